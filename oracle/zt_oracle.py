@@ -323,12 +323,19 @@ def warp_tensor(flow, img):
     return F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
 
 
+def _fma32(a, b, c):
+    """fp32 fused multiply-add (one rounding), emulated through float64 (products of two fp32 are exact there)."""
+    return (a.double() * b.double() + c.double()).float()
+
+
 def warp_taps(flow, h_dst, w_dst):
-    """Integer tap indices (x0, y0 = floor of the unnormalised source coords) of warp_tensor's grid_sample:
-    ix = ((gx+1)*W-1)/2 in fp32, exactly as ATen computes it.  int32 [B,h_dst,w_dst,2]."""
+    """Integer tap indices (x0, y0) of warp_tensor's grid_sample, with ATen's CPU arithmetic
+    (GridSamplerKernel.cpp, align_corners=False): ix = fma(gx + 1, W/2, -0.5); x0 = floor(ix).
+    Established bit-for-bit against torch 2.10 CPU in the build container.  int32 [B,h_dst,w_dst,2]."""
     grid = warp_coords(flow, h_dst, w_dst)
-    ix = ((grid[..., 0] + 1) * w_dst - 1) / 2
-    iy = ((grid[..., 1] + 1) * h_dst - 1) / 2
+    half = torch.tensor(-0.5)
+    ix = _fma32(grid[..., 0] + 1, torch.tensor(w_dst / 2.0, dtype=torch.float32), half)
+    iy = _fma32(grid[..., 1] + 1, torch.tensor(h_dst / 2.0, dtype=torch.float32), half)
     return torch.stack([torch.floor(ix), torch.floor(iy)], dim=-1).to(torch.int32)
 
 

@@ -101,7 +101,7 @@ def test_ops(oracle, synth, golden):
     assert abs(float(oracle.smooth_loss(x * 0.2, y)) - float(g["smooth"])) < 1e-5 * float(g["smooth"])
     assert abs(float(oracle.tv_loss(y)) - float(g["tv"])) < 1e-5 * float(g["tv"])
     flow = torch.from_numpy(g["warp_flow"])
-    assert np.array_equal(oracle.warp_tensor(flow, x).numpy(), g["warp_out"])
+    assert np.array_equal(oracle.warp_tensor(flow, torch.from_numpy(g["warp_img"])).numpy(), g["warp_out"])
     f1 = torch.from_numpy(synth.normal("ops.f1", (1, 256, 16, 24), 0.0, 1.0, 7))
     f2 = torch.from_numpy(synth.normal("ops.f2", (1, 256, 16, 24), 0.0, 1.0, 7))
     pyr = oracle.corr_pyramid(f1, f2)

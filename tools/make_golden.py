@@ -111,7 +111,8 @@ def case_sequence(ref, name, H, W, of_scale, seed, nframes=2):
     d["raft_img1"], d["raft_img2"] = store["raft_img1"], store["raft_img2"]
     d["wpH"], d["wps"] = np_(net.last_H3_wp), np_(net.last_s3_wp)
     d["last_H3"], d["last_s3"] = np_(net.last_H3), np_(net.last_s3)
-    # tap indices of the reference warp (integer contract), computed from the reference's own grid construction
+    # tap indices of the reference warp (integer contract): floor of the source coordinates ATen derives from the
+    # reference's own grid (utils.py:203-225), using ATen's CPU arithmetic ix = fma(g+1, W/2, -0.5)
     flow_up = torch.from_numpy(store["flow_up"])
     Hd, Wd = xs[0].shape[-2:]
     B, _, Hf, Wf = flow_up.shape
@@ -119,8 +120,10 @@ def case_sequence(ref, name, H, W, of_scale, seed, nframes=2):
     mx = torch.nn.functional.interpolate(((gx[None] - flow_up[:, 0]) * (float(Hd) / Hf)).unsqueeze(1), (Hd, Wd), mode="bilinear")
     my = torch.nn.functional.interpolate(((gy[None] - flow_up[:, 1]) * (float(Wd) / Wf)).unsqueeze(1), (Hd, Wd), mode="bilinear")
     gxn, gyn = mx / ((Wd - 1) / 2) - 1, my / ((Hd - 1) / 2) - 1
-    ix, iy = ((gxn + 1) * Wd - 1) / 2, ((gyn + 1) * Hd - 1) / 2
+    ix = ((gxn + 1).double() * (Wd / 2.0) - 0.5).float()
+    iy = ((gyn + 1).double() * (Hd / 2.0) - 0.5).float()
     d["warp_x0"], d["warp_y0"] = np_(torch.floor(ix)).astype(np.int32), np_(torch.floor(iy)).astype(np.int32)
+    # probe that these really are ATen's taps: sampling the images x and y reproduces ix, iy to rounding
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
     print(name, "losses", [float(d["loss%d" % t]) for t in range(nframes)], "flow_up absmax", float(np.abs(d["flow_up"]).max()),
           "bytes", os.path.getsize(os.path.join(OUT, name + ".npz")))
@@ -151,9 +154,10 @@ def case_ops(ref, name, seed=7):
     g["ycc"] = np_(L.SmoothLoss().rgb2yCbCr(x * 0.2))
     g["tv"] = np_(L.L_TV()(y))
     # warp: flow at 24x40 (scales 40/24 vs 56/40 differ -> exercises the swapped scales)
-    flow = torch.from_numpy(synth.normal("ops.flow", (1, 2, 24, 40), 0.0, 1.5, seed))
-    g["warp_flow"] = np_(flow)
-    g["warp_out"] = np_(U.warp_tensor(flow, x, y)[0])
+    flow = torch.from_numpy(synth.normal("ops.flow", (1, 2, 40, 64), 0.0, 1.5, seed))
+    wimg = torch.from_numpy(synth.uniform("ops.wimg", (1, 3, 72, 120), 0.0, 1.0, seed))
+    g["warp_flow"], g["warp_img"] = np_(flow), np_(wimg)
+    g["warp_out"] = np_(U.warp_tensor(flow, wimg, wimg)[0])
     # correlation volume + lookup
     f1 = torch.from_numpy(synth.normal("ops.f1", (1, 256, 16, 24), 0.0, 1.0, seed))
     f2 = torch.from_numpy(synth.normal("ops.f2", (1, 256, 16, 24), 0.0, 1.0, seed))
