@@ -1,0 +1,52 @@
+/* C ABI of libzerotig_hip.so -- the drop-in boundary for the Zero-TIG hot path on MI355X (gfx950).
+ *
+ * The reference has no FFI: its seam is the Python surface (model.model.Network / loss.LossFunction / utils.utils,
+ * SURVEY 8(b)).  The one native hook it anticipates is `alt_cuda_corr.forward` (model/RAFT/corr.py:86).  Each entry
+ * point below replaces the ATen call(s) of the cited reference lines.  Conventions:
+ *   - plain pointers to DEVICE memory + sizes; no torch types; the caller owns every buffer (inputs, outputs,
+ *     workspaces) and keeps it alive until the stream reaches the next op; nothing here allocates or synchronises;
+ *   - every function enqueues on `stream` (hipStream_t passed as void*) and returns 0, a hipError_t, or 1001
+ *     (invalid argument); the Python host raises RuntimeError on non-zero (zero-tig_amd/lib.py);
+ *   - "planar" = [C][H][W] fp32 (the reference's NCHW with N == 1); "nhwc" = [N][H][W][ld] fp32 with an explicit
+ *     channel stride `ld` so channel slices of wider buffers can be addressed without copies.
+ */
+#ifndef ZEROTIG_HIP_H
+#define ZEROTIG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* zt_stream_t;
+
+/* utils/utils.py:203-230 warp_tensor x2 (model.py:249-250), fused.  flow: planar [2][Hf][Wf]; imgA/imgB/outA/outB: planar
+ * [C][H][W] (imgB/outB may both be NULL); taps: optional int32 [H][W][2] = floor of the source coordinates (x0,y0). */
+int zt_warp2_f32(const float* flow, int Hf, int Wf, const float* imgA, const float* imgB, float* outA, float* outB,
+                 int* taps, int C, int H, int W, zt_stream_t stream);
+
+
+/* ---- stencil primitives on planar tensors (zt_stencil.hip) ------------------------------------------------ */
+/* utils/utils.py:15-24 pair_downsampler: o1 = (x[2y,2x+1]+x[2y+1,2x])/2, o2 = (x[2y,2x]+x[2y+1,2x+1])/2; outputs [C][H/2][W/2] */
+int zt_pair_down_f32(const float* src, float* o1, float* o2, int C, int H, int W, zt_stream_t stream);
+/* adjoint of the above: dst[C][H][W] (+)= pd^T(g1, g2) */
+int zt_pair_down_adj_f32(const float* g1, const float* g2, float* dst, int C, int H, int W, int accumulate, zt_stream_t stream);
+/* utils/utils.py:52-58 blur: reflect-pad 10 + 21x21 Gaussian, as two 21-tap passes; taps21_host: HOST pointer to the 1-D factor */
+int zt_blur21_f32(const float* src, float* tmp, float* dst, const float* taps21_host, int C, int H, int W, zt_stream_t stream);
+int zt_blur21_adj_f32(const float* g, float* tmp, float* dst, const float* taps21_host, int C, int H, int W, int accumulate, zt_stream_t stream);
+/* utils/utils.py:41-50 LocalMean (reflect-pad 2, 5x5 mean) and its adjoint (dst (+)= scale * LM^T(src)) */
+int zt_box5_reflect_f32(const float* src, float* dst, int C, int H, int W, zt_stream_t stream);
+int zt_box5_reflect_adj_f32(const float* src, float* dst, int C, int H, int W, float scale, int accumulate, zt_stream_t stream);
+/* utils/utils.py:60-79 calculate_local_variance of x = a - b (b may be NULL): D = x - box0(x)/25 (saved for backward, may be NULL), V = box0(D^2)/25 */
+int zt_localvar_fwd_f32(const float* a, const float* b, float* D, float* V, int C, int H, int W, zt_stream_t stream);
+/* backward: xbar (+)= sign * (E - box0(E)/25), E = 2 D box0(gV)/25 */
+int zt_localvar_bwd_f32(const float* D, const float* gV, float* xbar, int C, int H, int W, float sign, int accumulate, zt_stream_t stream);
+/* loss.py:99-136 TextureDifference: a, b planar [3][H][W] -> mask [H][W] in {0,1}; ratio (optional) = 2 s1 s2 / (s1^2+s2^2+1e-5) */
+int zt_texture_mask_f32(const float* a, const float* b, float* mask, float* ratio, int H, int W, zt_stream_t stream);
+/* loss.py:178-190 SmoothLoss.rgb2yCbCr over the flat memory (nelem = 3*H*W) */
+int zt_ycc_flat_f32(const float* src, float* dst, long long nelem, zt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

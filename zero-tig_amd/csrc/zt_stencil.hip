@@ -1,0 +1,376 @@
+// Stencil primitives of the Zero-TIG hot path on planar fp32 [C][H][W] tensors, with the adjoints the
+// hand-written backward pass needs.  All are HBM-bound (a few reads + one write per element).
+//   pair_downsampler      utils/utils.py:15-24
+//   blur (21x21 Gaussian) utils/utils.py:26-39, 52-58      (rank-1 kernel -> two 21-tap passes)
+//   LocalMean             utils/utils.py:41-50
+//   calculate_local_variance utils/utils.py:60-79
+//   TextureDifference     loss.py:99-136
+//   SmoothLoss.rgb2yCbCr  loss.py:178-190
+#include "zt_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ pair downsample
+__global__ void __launch_bounds__(256) pair_down_kernel(const float* __restrict__ src, float* __restrict__ o1,
+                                                        float* __restrict__ o2, int C, int H, int W, int h, int w) {
+  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= w || y >= h) return;
+  for (int c = 0; c < C; ++c) {
+    const float* p = src + (size_t)c * H * W + (size_t)(2 * y) * W + 2 * x;
+    float a = p[0], b = p[1], cc = p[W], d = p[W + 1];
+    o1[(size_t)c * h * w + (size_t)y * w + x] = 0.5f * b + 0.5f * cc;
+    o2[(size_t)c * h * w + (size_t)y * w + x] = 0.5f * a + 0.5f * d;
+  }
+}
+
+// dst (+)= adjoint(pair_down)(g1, g2); rows/cols beyond 2h/2w receive zero
+__global__ void __launch_bounds__(256) pair_down_adj_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                            float* __restrict__ dst, int C, int H, int W, int h, int w,
+                                                            int accumulate) {
+  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= W || y >= H) return;
+  int hy = y >> 1, hx = x >> 1;
+  bool inside = hy < h && hx < w;
+  bool diag = ((y ^ x) & 1) == 0;       // (even,even) and (odd,odd) feed output 2; the anti-diagonal feeds output 1
+  for (int c = 0; c < C; ++c) {
+    float v = 0.f;
+    if (inside) v = 0.5f * (diag ? g2 : g1)[(size_t)c * h * w + (size_t)hy * w + hx];
+    size_t o = (size_t)c * H * W + (size_t)y * W + x;
+    dst[o] = accumulate ? dst[o] + v : v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 21-tap separable blur
+struct Taps21 {
+  float t[21];
+};
+
+template <bool VERT>
+__global__ void __launch_bounds__(256) blur_pass_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                        int H, int W, Taps21 k) {
+  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= W || y >= H) return;
+  for (int c = 0; c < C; ++c) {
+    const float* p = src + (size_t)c * H * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 21; ++j) {
+      int yy = VERT ? zt_reflect(y + j - 10, H) : y;
+      int xx = VERT ? x : zt_reflect(x + j - 10, W);
+      acc = fmaf(k.t[j], p[(size_t)yy * W + xx], acc);
+    }
+    dst[(size_t)c * H * W + (size_t)y * W + x] = acc;
+  }
+}
+
+// adjoint of one reflect-padded pass: g_ext(u) = sum_j t_j * gy(u - j) on the extended domain, folded back
+template <bool VERT>
+__device__ __forceinline__ float blur_ext(const float* __restrict__ p, int fixed, int u, int n, int W, const Taps21& k) {
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 21; ++j) {
+    int i = u - (j - 10);
+    if (i >= 0 && i < n) acc = fmaf(k.t[j], VERT ? p[(size_t)i * W + fixed] : p[(size_t)fixed * W + i], acc);
+  }
+  return acc;
+}
+
+template <bool VERT>
+__global__ void __launch_bounds__(256) blur_pass_adj_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            int C, int H, int W, Taps21 k, int accumulate) {
+  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= W || y >= H) return;
+  int n = VERT ? H : W, kk = VERT ? y : x, fixed = VERT ? x : y;
+  for (int c = 0; c < C; ++c) {
+    const float* p = src + (size_t)c * H * W;
+    float acc = blur_ext<VERT>(p, fixed, kk, n, W, k);
+    if (kk >= 1 && kk <= 10) acc += blur_ext<VERT>(p, fixed, -kk, n, W, k);
+    if (kk <= n - 2 && kk >= n - 11) acc += blur_ext<VERT>(p, fixed, 2 * (n - 1) - kk, n, W, k);
+    size_t o = (size_t)c * H * W + (size_t)y * W + x;
+    dst[o] = accumulate ? dst[o] + acc : acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 5x5 reflect mean
+__global__ void __launch_bounds__(256) box5_reflect_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                           int H, int W) {
+  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= W || y >= H) return;
+  for (int c = 0; c < C; ++c) {
+    const float* p = src + (size_t)c * H * W;
+    float acc = 0.f;
+    for (int dy = -2; dy <= 2; ++dy) {
+      int yy = zt_reflect(y + dy, H);
+      for (int dx = -2; dx <= 2; ++dx) acc += p[(size_t)yy * W + zt_reflect(x + dx, W)];
+    }
+    dst[(size_t)c * H * W + (size_t)y * W + x] = acc / 25.f;
+  }
+}
+
+__device__ __forceinline__ int fold_sources(int k, int n, int* u) {
+  int m = 0;
+  u[m++] = k;
+  if (k >= 1 && k <= 2) u[m++] = -k;
+  if (k <= n - 2 && k >= n - 3) u[m++] = 2 * (n - 1) - k;
+  return m;
+}
+
+// dst = scale_out * adjoint(box5_reflect)(src)   (accumulate: dst += ...)
+__global__ void __launch_bounds__(256) box5_reflect_adj_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                               int C, int H, int W, float scale, int accumulate) {
+  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= W || y >= H) return;
+  int uy[3], ux[3];
+  int ny = fold_sources(y, H, uy), nx = fold_sources(x, W, ux);
+  for (int c = 0; c < C; ++c) {
+    const float* p = src + (size_t)c * H * W;
+    float acc = 0.f;
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b)
+        for (int dy = -2; dy <= 2; ++dy) {
+          int yy = uy[a] - dy;
+          if (yy < 0 || yy >= H) continue;
+          for (int dx = -2; dx <= 2; ++dx) {
+            int xx = ux[b] - dx;
+            if (xx >= 0 && xx < W) acc += p[(size_t)yy * W + xx];
+          }
+        }
+    acc = acc / 25.f * scale;
+    size_t o = (size_t)c * H * W + (size_t)y * W + x;
+    dst[o] = accumulate ? dst[o] + acc : acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ local variance (zero pad)
+// D = x - box0(x)/25 ; V = box0(D^2)/25     (x = a - b when b != nullptr)
+#define LV_TX 32
+#define LV_TY 8
+__global__ void __launch_bounds__(256) localvar_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ D, float* __restrict__ V, int C, int H,
+                                                           int W) {
+  __shared__ float xs[LV_TY + 8][LV_TX + 8];
+  __shared__ float ds[LV_TY + 4][LV_TX + 4];
+  int c = blockIdx.z;
+  int x0 = blockIdx.x * LV_TX, y0 = blockIdx.y * LV_TY;
+  int tid = threadIdx.y * LV_TX + threadIdx.x;
+  const float* pa = a + (size_t)c * H * W;
+  const float* pb = b ? b + (size_t)c * H * W : nullptr;
+  for (int i = tid; i < (LV_TY + 8) * (LV_TX + 8); i += 256) {
+    int ly = i / (LV_TX + 8), lx = i % (LV_TX + 8);
+    int gy = y0 + ly - 4, gx = x0 + lx - 4;
+    float v = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      v = pa[(size_t)gy * W + gx];
+      if (pb) v -= pb[(size_t)gy * W + gx];
+    }
+    xs[ly][lx] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < (LV_TY + 4) * (LV_TX + 4); i += 256) {
+    int ly = i / (LV_TX + 4), lx = i % (LV_TX + 4);
+    int gy = y0 + ly - 2, gx = x0 + lx - 2;
+    float d = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      float s = 0.f;
+      for (int dy = 0; dy < 5; ++dy)
+        for (int dx = 0; dx < 5; ++dx) s += xs[ly + dy][lx + dx];
+      d = xs[ly + 2][lx + 2] - s / 25.f;
+    }
+    ds[ly][lx] = d;
+  }
+  __syncthreads();
+  int gx = x0 + threadIdx.x, gy = y0 + threadIdx.y;
+  if (gx < W && gy < H) {
+    float s = 0.f;
+    for (int dy = 0; dy < 5; ++dy)
+      for (int dx = 0; dx < 5; ++dx) {
+        float d = ds[threadIdx.y + dy][threadIdx.x + dx];
+        s += d * d;
+      }
+    size_t o = (size_t)c * H * W + (size_t)gy * W + gx;
+    V[o] = s / 25.f;
+    if (D) D[o] = ds[threadIdx.y + 2][threadIdx.x + 2];
+  }
+}
+
+// xbar (+)= sign * (E - box0(E)/25),  E = 2 * D * box0(gV)/25
+__global__ void __launch_bounds__(256) localvar_bwd_kernel(const float* __restrict__ D, const float* __restrict__ gV,
+                                                           float* __restrict__ xbar, int C, int H, int W, float sign,
+                                                           int accumulate) {
+  __shared__ float gs[LV_TY + 8][LV_TX + 8];
+  __shared__ float es[LV_TY + 4][LV_TX + 4];
+  int c = blockIdx.z;
+  int x0 = blockIdx.x * LV_TX, y0 = blockIdx.y * LV_TY;
+  int tid = threadIdx.y * LV_TX + threadIdx.x;
+  const float* pg = gV + (size_t)c * H * W;
+  const float* pd = D + (size_t)c * H * W;
+  for (int i = tid; i < (LV_TY + 8) * (LV_TX + 8); i += 256) {
+    int ly = i / (LV_TX + 8), lx = i % (LV_TX + 8);
+    int gy = y0 + ly - 4, gx = x0 + lx - 4;
+    gs[ly][lx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? pg[(size_t)gy * W + gx] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < (LV_TY + 4) * (LV_TX + 4); i += 256) {
+    int ly = i / (LV_TX + 4), lx = i % (LV_TX + 4);
+    int gy = y0 + ly - 2, gx = x0 + lx - 2;
+    float e = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      float s = 0.f;
+      for (int dy = 0; dy < 5; ++dy)
+        for (int dx = 0; dx < 5; ++dx) s += gs[ly + dy][lx + dx];
+      e = 2.f * pd[(size_t)gy * W + gx] * (s / 25.f);
+    }
+    es[ly][lx] = e;
+  }
+  __syncthreads();
+  int gx = x0 + threadIdx.x, gy = y0 + threadIdx.y;
+  if (gx < W && gy < H) {
+    float s = 0.f;
+    for (int dy = 0; dy < 5; ++dy)
+      for (int dx = 0; dx < 5; ++dx) s += es[threadIdx.y + dy][threadIdx.x + dx];
+    float v = sign * (es[threadIdx.y + 2][threadIdx.x + 2] - s / 25.f);
+    size_t o = (size_t)c * H * W + (size_t)gy * W + gx;
+    xbar[o] = accumulate ? xbar[o] + v : v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ texture mask
+__device__ __forceinline__ float gray144(const float* __restrict__ p, size_t plane, size_t o) {
+  return 0.144f * p[o] + 0.587f * p[plane + o] + 0.299f * p[2 * plane + o];
+}
+
+__device__ __forceinline__ float local_std5(const float* __restrict__ p, int x, int y, int H, int W) {
+  size_t plane = (size_t)H * W;
+  float v[25];
+  float s = 0.f;
+  int n = 0;
+  for (int dy = -2; dy <= 2; ++dy) {
+    int yy = zt_reflect(y + dy, H);
+    for (int dx = -2; dx <= 2; ++dx) {
+      float g = gray144(p, plane, (size_t)yy * W + zt_reflect(x + dx, W));
+      v[n++] = g;
+      s += g;
+    }
+  }
+  float mu = s / 25.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 25; ++i) {
+    float d = v[i] - mu;
+    q += d * d;
+  }
+  return sqrtf(q / 25.f + 1e-9f);
+}
+
+__global__ void __launch_bounds__(256) texture_mask_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ mask, float* __restrict__ ratio, int H,
+                                                           int W) {
+  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= W || y >= H) return;
+  float s1 = local_std5(a, x, y, H, W), s2 = local_std5(b, x, y, H, W);
+  float r = (2.f * s1 * s2) / (s1 * s1 + s2 * s2 + 1e-5f);
+  size_t o = (size_t)y * W + x;
+  mask[o] = r > 0.975f ? 1.f : 0.f;
+  if (ratio) ratio[o] = r;
+}
+
+// ------------------------------------------------------------------------------------------------ "YCbCr" over flat memory
+__global__ void __launch_bounds__(256) ycc_flat_kernel(const float* __restrict__ src, float* __restrict__ dst, long long ntriples) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntriples) return;
+  float r = src[3 * t], g = src[3 * t + 1], b = src[3 * t + 2];
+  // im_flat.mm(mat) + bias, mat rows = input element, cols = output element (loss.py:182-186)
+  dst[3 * t + 0] = (r * 0.257f + g * 0.564f + b * 0.098f) + (float)(16.0 / 255.0);
+  dst[3 * t + 1] = (r * -0.148f + g * -0.291f + b * 0.439f) + (float)(128.0 / 255.0);
+  dst[3 * t + 2] = (r * 0.439f + g * -0.368f + b * -0.071f) + (float)(128.0 / 255.0);
+}
+
+inline dim3 grid2d(int W, int H) { return dim3(zt_cdiv(W, 64), zt_cdiv(H, 4)); }
+
+}  // namespace
+
+extern "C" int zt_pair_down_f32(const float* src, float* o1, float* o2, int C, int H, int W, hipStream_t stream) {
+  ZT_REQUIRE(src && o1 && o2 && C > 0 && H >= 2 && W >= 2);
+  int h = H / 2, w = W / 2;
+  hipLaunchKernelGGL(pair_down_kernel, grid2d(w, h), dim3(64, 4), 0, stream, src, o1, o2, C, H, W, h, w);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_pair_down_adj_f32(const float* g1, const float* g2, float* dst, int C, int H, int W, int accumulate,
+                                    hipStream_t stream) {
+  ZT_REQUIRE(g1 && g2 && dst && C > 0 && H >= 2 && W >= 2);
+  hipLaunchKernelGGL(pair_down_adj_kernel, grid2d(W, H), dim3(64, 4), 0, stream, g1, g2, dst, C, H, W, H / 2, W / 2, accumulate);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_blur21_f32(const float* src, float* tmp, float* dst, const float* taps21_host, int C, int H, int W,
+                             hipStream_t stream) {
+  ZT_REQUIRE(src && tmp && dst && taps21_host && H > 10 && W > 10);
+  Taps21 k;
+  for (int i = 0; i < 21; ++i) k.t[i] = taps21_host[i];
+  hipLaunchKernelGGL(blur_pass_kernel<false>, grid2d(W, H), dim3(64, 4), 0, stream, src, tmp, C, H, W, k);
+  hipLaunchKernelGGL(blur_pass_kernel<true>, grid2d(W, H), dim3(64, 4), 0, stream, (const float*)tmp, dst, C, H, W, k);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_blur21_adj_f32(const float* g, float* tmp, float* dst, const float* taps21_host, int C, int H, int W,
+                                 int accumulate, hipStream_t stream) {
+  ZT_REQUIRE(g && tmp && dst && taps21_host && H > 21 && W > 21);
+  Taps21 k;
+  for (int i = 0; i < 21; ++i) k.t[i] = taps21_host[i];
+  hipLaunchKernelGGL(blur_pass_adj_kernel<true>, grid2d(W, H), dim3(64, 4), 0, stream, g, tmp, C, H, W, k, 0);
+  hipLaunchKernelGGL(blur_pass_adj_kernel<false>, grid2d(W, H), dim3(64, 4), 0, stream, (const float*)tmp, dst, C, H, W, k, accumulate);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_box5_reflect_f32(const float* src, float* dst, int C, int H, int W, hipStream_t stream) {
+  ZT_REQUIRE(src && dst && H > 2 && W > 2);
+  hipLaunchKernelGGL(box5_reflect_kernel, grid2d(W, H), dim3(64, 4), 0, stream, src, dst, C, H, W);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_box5_reflect_adj_f32(const float* src, float* dst, int C, int H, int W, float scale, int accumulate,
+                                       hipStream_t stream) {
+  ZT_REQUIRE(src && dst && H > 5 && W > 5);
+  hipLaunchKernelGGL(box5_reflect_adj_kernel, grid2d(W, H), dim3(64, 4), 0, stream, src, dst, C, H, W, scale, accumulate);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_localvar_fwd_f32(const float* a, const float* b, float* D, float* V, int C, int H, int W,
+                                   hipStream_t stream) {
+  ZT_REQUIRE(a && V && C > 0);
+  dim3 grid(zt_cdiv(W, LV_TX), zt_cdiv(H, LV_TY), C);
+  hipLaunchKernelGGL(localvar_fwd_kernel, grid, dim3(LV_TX, LV_TY), 0, stream, a, b, D, V, C, H, W);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_localvar_bwd_f32(const float* D, const float* gV, float* xbar, int C, int H, int W, float sign,
+                                   int accumulate, hipStream_t stream) {
+  ZT_REQUIRE(D && gV && xbar && C > 0);
+  dim3 grid(zt_cdiv(W, LV_TX), zt_cdiv(H, LV_TY), C);
+  hipLaunchKernelGGL(localvar_bwd_kernel, grid, dim3(LV_TX, LV_TY), 0, stream, D, gV, xbar, C, H, W, sign, accumulate);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_texture_mask_f32(const float* a, const float* b, float* mask, float* ratio, int H, int W,
+                                   hipStream_t stream) {
+  ZT_REQUIRE(a && b && mask && H > 2 && W > 2);
+  hipLaunchKernelGGL(texture_mask_kernel, grid2d(W, H), dim3(64, 4), 0, stream, a, b, mask, ratio, H, W);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_ycc_flat_f32(const float* src, float* dst, long long nelem, hipStream_t stream) {
+  ZT_REQUIRE(src && dst && nelem % 3 == 0);
+  long long nt = nelem / 3;
+  hipLaunchKernelGGL(ycc_flat_kernel, dim3((unsigned)zt_cdivl(nt, 256)), dim3(256), 0, stream, src, dst, nt);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
