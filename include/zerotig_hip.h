@@ -46,6 +46,29 @@ int zt_texture_mask_f32(const float* a, const float* b, float* mask, float* rati
 /* loss.py:178-190 SmoothLoss.rgb2yCbCr over the flat memory (nelem = 3*H*W) */
 int zt_ycc_flat_f32(const float* src, float* dst, long long nelem, zt_stream_t stream);
 
+
+/* ---- MFMA implicit-GEMM convolution family (zt_conv.hip) -----------------------------------------------------
+ * Replaces F.conv2d of model.py:20-27, 36-43, 55-80, every conv of model/RAFT/{extractor,update}.py, and (as a 1x1
+ * conv whose "weights" are fmap2) the all-pairs matmul of corr.py:52-60.
+ * x: nhwc [N][H][W][ldx] (first Cin channels used; channels >= csplit come from x2 [..][ldx2] when x2 != NULL);
+ * w: device layout [KH*KW][Cin][ldw] (zt_repack_conv_weight_f32); y: nhwc [N][Ho][Wo][ldy], or planar
+ * [N][Cout] planes of pitch ldy when out_planar; y = act(alpha * (conv + bias)) then epi: 0 none,
+ * 1: *= LeakyReLU'(aux) (aux>0 ? 1 : 0.2), 2: *= (aux>0), 3: += aux  (aux nhwc, stride ldaux).
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 sigmoid, 4 tanh, 5 clamp(sigmoid, 1e-4, 1).
+ * Supported (KH,KW,stride): (3,3,1|2) (1,1,1|2) (1,5,1) (5,1,1) (7,7,1|2). */
+int zt_conv2d_nhwc_f32(const float* x, const float* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
+                       const float* w, int ldw, const float* bias, float* y, int ldy, int out_planar, int Cout, int KH,
+                       int KW, int stride, int padH, int padW, int act, float alpha, const float* aux, int ldaux,
+                       int epi, zt_stream_t stream);
+/* weight gradient of a stride-1 "same" conv (autograd of the above): grad_w [Cout][Cin][KH][KW] (torch layout)
+ * (+)= sum_p x[p+tap][ci] dz[p][co]; slab: workspace for per-workgroup partials (deterministic reduction). */
+int zt_conv2d_wgrad_nhwc_f32(const float* x, int ldx, const float* dz, int lddz, int H, int W, int Cin, int Cout, int KH,
+                             int KW, float* slab, size_t slab_bytes, float* grad_w, int accumulate, zt_stream_t stream);
+/* torch weight [Cout][Cin][KH][KW] -> device layout [tap][Cin][ldw] at column offset co_off (transpose_flip = 0), or the
+ * data-gradient operator [tap flipped][Cout][ldw] with in/out channels exchanged (transpose_flip = 1). */
+int zt_repack_conv_weight_f32(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int ldw, int co_off,
+                              int transpose_flip, zt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

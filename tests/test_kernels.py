@@ -81,3 +81,109 @@ def test_stencils(backend, oracle):
     assert (m.cpu().numpy() != g["texmask"]).mean() <= 1e-3
     # flat "YCbCr"
     assert maxerr(ops.ycc_flat(x * 0.2), torch.from_numpy(g["ycc"])) < 1e-6
+
+
+def _nhwc(t, ld=None):
+    """NCHW cpu tensor -> NHWC (optionally padded to ld channels)"""
+    n = t.permute(0, 2, 3, 1).contiguous()
+    if ld is not None and ld != n.shape[-1]:
+        n = torch.cat([n, torch.zeros(*n.shape[:3], ld - n.shape[-1])], -1).contiguous()
+    return n
+
+
+CONV_CASES = [
+    # Cin, Cout, KH, KW, stride, pad, H, W, act
+    (3, 48, 3, 3, 1, (1, 1), 9, 37, "lrelu"),       # thin-in first layer (Denoise_1.conv1), ragged tile edges
+    (48, 48, 3, 3, 1, (1, 1), 8, 33, "lrelu"),      # Denoise conv2 (NT=3)
+    (64, 64, 3, 3, 1, (1, 1), 6, 40, "relu"),       # Enhancer body (NT=4)
+    (64, 3, 3, 3, 1, (1, 1), 7, 20, "sigmoid_clamp"),   # thin-out (NT=1)
+    (48, 6, 1, 1, 1, (0, 0), 5, 19, None),
+    (3, 64, 7, 7, 2, (3, 3), 20, 36, None),         # RAFT encoder stem
+    (64, 96, 3, 3, 2, (1, 1), 11, 21, None),        # stride-2 residual conv
+    (64, 96, 1, 1, 2, (0, 0), 11, 21, None),        # stride-2 downsample
+    (40, 32, 1, 5, 1, (0, 2), 6, 18, "sigmoid"),    # SepConvGRU horizontal (reduced channels)
+    (40, 32, 5, 1, 1, (2, 0), 6, 18, "tanh"),       # SepConvGRU vertical
+    (2, 128, 7, 7, 1, (3, 3), 6, 10, "relu"),       # convf1
+    (20, 126, 3, 3, 1, (1, 1), 5, 9, "relu"),       # ragged Cin chunk + ragged Cout
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "c%d-%d_k%dx%d_s%d" % c[:5])
+def test_conv_fwd(backend, case):
+    import torch.nn.functional as F
+    ops, dev, name = backend
+    Cin, Cout, KH, KW, stride, pad, H, W, act = case
+    g = torch.Generator().manual_seed(Cin * 131 + Cout)
+    N = 2 if Cin == 3 and KH == 7 else 1
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    ref = {None: lambda t: t, "relu": torch.relu, "lrelu": lambda t: F.leaky_relu(t, 0.2), "sigmoid": torch.sigmoid,
+           "tanh": torch.tanh, "sigmoid_clamp": lambda t: torch.clamp(torch.sigmoid(t), 1e-4, 1)}[act](ref)
+    ld = (Cin + 3) // 4 * 4
+    xd = _nhwc(x, ld).to(dev)
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    wd = ops.repack_weight(w.to(dev))
+    y = ops.conv2d(CV(xd, 0, Cin), wd, b.to(dev), Cout, KH, KW, stride, pad, act)
+    got = y.cpu()[..., :Cout].permute(0, 3, 1, 2)
+    assert maxerr(got, ref) < 2e-5, maxerr(got, ref)
+    if Cout <= 6:   # planar epilogue used by the thin output layers
+        yp = ops.conv2d(CV(xd, 0, Cin), wd, b.to(dev), Cout, KH, KW, stride, pad, act, out_planar=True)
+        assert maxerr(yp, ref) < 2e-5
+
+
+def test_conv_split_input_alpha_epi(backend):
+    import torch.nn.functional as F
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    g = torch.Generator().manual_seed(5)
+    H, W = 5, 21
+    xa, xb = torch.randn(1, 16, H, W, generator=g), torch.randn(1, 24, H, W, generator=g)
+    w = torch.randn(32, 40, 3, 3, generator=g) * 0.05
+    aux = torch.randn(1, 32, H, W, generator=g)
+    big = torch.zeros(1, H, W, 64)
+    big[..., 8:32] = _nhwc(xb)
+    ref = 0.25 * F.conv2d(torch.cat([xa, xb], 1), w, None, padding=1)
+    wd = ops.repack_weight(w.to(dev))
+    auxd = _nhwc(aux).to(dev)
+    for epi, fn in ((0, lambda r: r), (1, lambda r: r * torch.where(aux > 0, 1.0, 0.2)), (2, lambda r: r * (aux > 0)), (3, lambda r: r + aux)):
+        out = torch.zeros(1, H, W, 48, device=dev)
+        ops.conv2d(CV(_nhwc(xa).to(dev)), wd, None, 32, 3, 3, 1, (1, 1), None, alpha=0.25, x2=CV(big.to(dev), 8, 24),
+                   out=CV(out, 16, 32), aux=auxd, epi=epi)
+        assert maxerr(out.cpu()[..., 16:48].permute(0, 3, 1, 2), fn(ref)) < 1e-5
+        assert float(out[..., :16].abs().max()) == 0.0
+    # data-gradient operator == conv with the transposed / flipped weights
+    xg = torch.randn(1, 40, H, W, generator=g, requires_grad=True)
+    dz = torch.randn(1, 32, H, W, generator=g)
+    (F.conv2d(xg, w, None, padding=1) * dz).sum().backward()
+    wdg = ops.repack_weight(w.to(dev), transpose_flip=True)
+    dx = ops.conv2d(CV(_nhwc(dz).to(dev)), wdg, None, 40, 3, 3, 1, (1, 1))
+    assert maxerr(dx.cpu().permute(0, 3, 1, 2), xg.grad) < 1e-5
+
+
+WGRAD_CASES = [(3, 48, 3, 4), (48, 48, 3, 48), (48, 3, 1, 48), (9, 64, 3, 12), (64, 64, 3, 64), (64, 3, 3, 64), (12, 48, 3, 12), (48, 6, 1, 48)]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "c%d-%d_k%d" % c[:3])
+def test_conv_wgrad(backend, case):
+    import torch.nn.functional as F
+    ops, dev, _ = backend
+    Cin, Cout, K, ldx = case
+    g = torch.Generator().manual_seed(Cin + 7 * Cout)
+    H, W = 9, 21
+    x = torch.randn(1, Cin, H, W, generator=g)
+    dz = torch.randn(1, Cout, H, W, generator=g)
+    w = torch.zeros(Cout, Cin, K, K, requires_grad=True)
+    (F.conv2d(x, w, None, padding=K // 2) * dz).sum().backward()
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    xd = CV(_nhwc(x, ldx).to(dev), 0, Cin)
+    dzd = CV(_nhwc(dz, (Cout + 3) // 4 * 4).to(dev), 0, Cout)
+    gw = torch.full((Cout, Cin, K, K), 7.0, device=dev)
+    ops.conv2d_wgrad(xd, dzd, Cout, K, K, gw, accumulate=False)
+    assert maxerr(gw, w.grad) < 5e-5, maxerr(gw, w.grad)
+    ops.conv2d_wgrad(xd, dzd, Cout, K, K, gw, accumulate=True)
+    assert maxerr(gw, 2 * w.grad) < 1e-4

@@ -1,0 +1,419 @@
+// Implicit-GEMM convolutions on the gfx950 matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32), for the
+// enhancement/denoising nets (reference model/model.py:15-81: conv2d of Denoise_1 / Denoise_2 / Enhancer), their
+// data- and weight-gradients, and every RAFT convolution (model/RAFT/extractor.py, update.py) incl. the all-pairs
+// correlation volume (corr.py:52-60, a 1x1 "convolution" whose weights are the second feature map).
+//
+// Layout: activations NHWC fp32 with explicit channel stride; weights [tap][Cin][ldw] (ldw = Cout rounded to 16).
+// GEMM view: M = output pixels (16 consecutive pixels of one row per MFMA tile), N = Cout, K = taps x Cin.
+// One workgroup = 4 waves = 4 output rows x 32 columns x (NT*16) output channels.  Per 16-channel input chunk the
+// halo tile is staged once in LDS as [ci][row][col] planes (plane stride == 16 mod 32 banks => both MFMA operand
+// reads are bank-conflict free), weights are staged per kernel row.
+#include "zt_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct ConvArgs {
+  const float* x;
+  const float* x2;
+  const float* w;
+  const float* bias;
+  const float* aux;
+  float* y;
+  int N, H, W, Cin, ldx, ldx2, csplit;
+  int Ho, Wo, Cout, ldy, ldw, ldaux;
+  int padH, padW;
+  int act, epi, out_planar;
+  float alpha;
+  int tilesX, tilesY;
+};
+
+constexpr int TH = 4, TW = 32, CK = 16;
+
+constexpr int plane_stride(int n) { return (n % 32 <= 16) ? n + (16 - n % 32) : n + (48 - n % 32); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case 1: return fmaxf(v, 0.f);
+    case 2: return v > 0.f ? v : 0.2f * v;
+    case 3: return 1.f / (1.f + expf(-v));
+    case 4: return tanhf(v);
+    case 5: return fminf(fmaxf(1.f / (1.f + expf(-v)), 0.0001f), 1.f);
+    default: return v;
+  }
+}
+
+template <int KH, int KW, int S, int NT>
+__global__ void __launch_bounds__(256) conv_mfma_f32_kernel(ConvArgs a) {
+  constexpr int IR = (TH - 1) * S + KH, IC = (TW - 1) * S + KW;
+  constexpr int PLANE = plane_stride(IR * IC);
+  constexpr int COP = plane_stride(NT * 16);
+  __shared__ float xs[CK * PLANE];
+  __shared__ float ws[KW * CK * COP];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x;
+  const int tx = t % a.tilesX;
+  t /= a.tilesX;
+  const int ty = t % a.tilesY;
+  const int n = t / a.tilesY;
+  const int co0 = blockIdx.y * (NT * 16);
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int gy0 = oy0 * S - a.padH, gx0 = ox0 * S - a.padW;
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+    __syncthreads();
+    // ---- stage the input halo tile for channels [c0, c0+16): 16 pixels x 4 channel-quads per 64 lanes
+    {
+      const bool second = a.x2 != nullptr && c0 >= a.csplit;
+      const float* src = second ? a.x2 : a.x;
+      const int ld = second ? a.ldx2 : a.ldx;
+      const int cbase = second ? c0 - a.csplit : c0;
+      const int climit = second ? a.Cin - a.csplit : (a.x2 ? a.csplit : a.Cin);
+      constexpr int NGRP = (IR * IC + 15) / 16;
+      for (int e = tid; e < NGRP * 64; e += 256) {
+        int p = ((e >> 6) << 4) + (e & 15);
+        int q = (e >> 4) & 3;
+        if (p < IR * IC) {
+          int iy = p / IC, ixx = p - iy * IC;
+          int gy = gy0 + iy, gx = gx0 + ixx;
+          int c = cbase + q * 4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < climit) {
+            const float* g = src + ((size_t)(n * a.H + gy) * a.W + gx) * ld + c;
+            if (c + 3 < climit) {
+              v = *reinterpret_cast<const float4*>(g);
+            } else {
+              v.x = g[0];
+              if (c + 1 < climit) v.y = g[1];
+              if (c + 2 < climit) v.z = g[2];
+            }
+          }
+          float* d = xs + (q * 4) * PLANE + p;
+          d[0] = v.x;
+          d[PLANE] = v.y;
+          d[2 * PLANE] = v.z;
+          d[3 * PLANE] = v.w;
+        }
+      }
+    }
+#pragma unroll 1
+    for (int ky = 0; ky < KH; ++ky) {
+      // ---- stage weights of kernel row ky for this channel chunk: ws[kx][ci][co]
+      constexpr int NW4 = KW * CK * NT * 4;
+      for (int e = tid; e < NW4; e += 256) {
+        int co4 = e % (NT * 4);
+        int r = e / (NT * 4);
+        int ci = r % CK, kx = r / CK;
+        int co = co0 + co4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + ci < a.Cin && co < a.ldw)
+          v = *reinterpret_cast<const float4*>(a.w + ((size_t)(ky * KW + kx) * a.Cin + c0 + ci) * a.ldw + co);
+        *reinterpret_cast<float4*>(ws + (kx * CK + ci) * COP + co4 * 4) = v;
+      }
+      __syncthreads();
+      const float* xrow = xs + (wave * S + ky) * IC;
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) {
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const int ci = k4 * 4 + l4;
+          float av[2], bv[NT];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) av[m] = xrow[ci * PLANE + (m * 16 + l15) * S + kx];
+#pragma unroll
+          for (int q = 0; q < NT; ++q) bv[q] = ws[(kx * CK + ci) * COP + q * 16 + l15];
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[q], acc[m][q], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: D[row = 4*(lane>>4)+j][col = lane&15] -> pixel (oy, ox0 + m*16 + row), channel co0 + q*16 + col
+  const int oy = oy0 + wave;
+  if (oy >= a.Ho) return;
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    const int co = co0 + q * 16 + l15;
+    if (co >= a.Cout) continue;
+    const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ox = ox0 + m * 16 + l4 * 4 + j;
+        if (ox >= a.Wo) continue;
+        float v = apply_act(a.alpha * (acc[m][q][j] + b), a.act);
+        const size_t pix = (size_t)(n * a.Ho + oy) * a.Wo + ox;
+        if (a.epi) {
+          float u = a.aux[pix * a.ldaux + co];
+          if (a.epi == 1) v *= (u > 0.f ? 1.f : 0.2f);
+          else if (a.epi == 2) v *= (u > 0.f ? 1.f : 0.f);
+          else v += u;
+        }
+        if (a.out_planar) a.y[((size_t)n * a.Cout + co) * a.ldy + (size_t)oy * a.Wo + ox] = v;
+        else a.y[pix * a.ldy + co] = v;
+      }
+    }
+  }
+}
+
+template <int KH, int KW, int S>
+int launch_conv(const ConvArgs& a, int NT, dim3 grid_base, hipStream_t stream) {
+  dim3 block(256);
+  int c16 = (a.Cout + 15) / 16;
+  dim3 grid(grid_base.x, (c16 + NT - 1) / NT);
+  switch (NT) {
+    case 1: hipLaunchKernelGGL((conv_mfma_f32_kernel<KH, KW, S, 1>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((conv_mfma_f32_kernel<KH, KW, S, 2>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((conv_mfma_f32_kernel<KH, KW, S, 3>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((conv_mfma_f32_kernel<KH, KW, S, 4>), grid, block, 0, stream, a); break;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[tap][ci][co] = sum_pixels x[p + tap][ci] * dz[p][co]      (stride 1, "same" padding)
+// GEMM view: M = ci, N = co, K = pixels.  Each workgroup walks pixel tiles (4 rows x 16 cols) grid-stride and keeps
+// its (tap, ci-tile) x co-tile accumulators in registers; partial slabs are summed by wgrad_reduce_kernel
+// (deterministic; no float atomics).
+struct WgradArgs {
+  const float* x;
+  const float* dz;
+  float* slab;
+  int H, W, Cin, ldx, Cout, lddz;
+  int tilesX, ntiles;
+};
+
+constexpr int WTH = 4, WTW = 16;
+
+template <int KH, int KW, int CT, int NT>
+__global__ void __launch_bounds__(256) wgrad_mfma_f32_kernel(WgradArgs a) {
+  constexpr int IR = WTH + KH - 1, IC = WTW + KW - 1;
+  constexpr int CIP = plane_stride(CT * 16), COP = plane_stride(NT * 16);
+  constexpr int NPAIR = KH * KW * CT;
+  constexpr int PPW = (NPAIR + 3) / 4;
+  __shared__ float xs[IR * IC * CIP];
+  __shared__ float zs[WTH * WTW * COP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  constexpr int padH = (KH - 1) / 2, padW = (KW - 1) / 2;
+
+  f32x4 acc[PPW][NT];
+#pragma unroll
+  for (int p = 0; p < PPW; ++p)
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[p][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const int oy0 = ty * WTH, ox0 = tx * WTW;
+    __syncthreads();
+    // stage x halo tile [pix][ci] (zero beyond the image / beyond Cin)
+    for (int e = tid; e < IR * IC * CT * 4; e += 256) {
+      int c4 = e % (CT * 4), p = e / (CT * 4);
+      int iy = p / IC, ixx = p - iy * IC;
+      int gy = oy0 - padH + iy, gx = ox0 - padW + ixx;
+      int c = c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Cin) {
+        const float* g = a.x + ((size_t)gy * a.W + gx) * a.ldx + c;
+        if (c + 3 < a.Cin) v = *reinterpret_cast<const float4*>(g);
+        else {
+          v.x = g[0];
+          if (c + 1 < a.Cin) v.y = g[1];
+          if (c + 2 < a.Cin) v.z = g[2];
+        }
+      }
+      *reinterpret_cast<float4*>(xs + p * CIP + c) = v;
+    }
+    for (int e = tid; e < WTH * WTW * NT * 4; e += 256) {
+      int c4 = e % (NT * 4), p = e / (NT * 4);
+      int iy = p / WTW, ixx = p - iy * WTW;
+      int gy = oy0 + iy, gx = ox0 + ixx;
+      int c = c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gy < a.H && gx < a.W && c < a.Cout) {
+        const float* g = a.dz + ((size_t)gy * a.W + gx) * a.lddz + c;
+        if (c + 3 < a.Cout) v = *reinterpret_cast<const float4*>(g);
+        else {
+          v.x = g[0];
+          if (c + 1 < a.Cout) v.y = g[1];
+          if (c + 2 < a.Cout) v.z = g[2];
+        }
+      }
+      *reinterpret_cast<float4*>(zs + p * COP + c) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < WTH; ++r) {
+#pragma unroll
+      for (int k4 = 0; k4 < WTW / 4; ++k4) {
+        const int col = k4 * 4 + l4;          // this lane's pixel (K index) within the row
+        float bv[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) bv[q] = zs[(r * WTW + col) * COP + q * 16 + l15];
+#pragma unroll
+        for (int pi = 0; pi < PPW; ++pi) {
+          const int pr = wave + 4 * pi;
+          if (pr < NPAIR) {                    // wave-uniform
+            const int tap = pr / CT, cit = pr - tap * CT;
+            const int ky = tap / KW, kx = tap - ky * KW;
+            float av = xs[((r + ky) * IC + col + kx) * CIP + cit * 16 + l15];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc[pi][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[q], acc[pi][q], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // slab[block][tap][ci16][co16]
+  float* out = a.slab + (size_t)blockIdx.x * (KH * KW * CT * 16 * NT * 16);
+#pragma unroll
+  for (int pi = 0; pi < PPW; ++pi) {
+    const int pr = wave + 4 * pi;
+    if (pr < NPAIR) {
+      const int tap = pr / CT, cit = pr - tap * CT;
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          out[((size_t)tap * CT * 16 + cit * 16 + l4 * 4 + j) * (NT * 16) + q * 16 + l15] = acc[pi][q][j];
+    }
+  }
+}
+
+// grad[co][ci][ky][kx] (+)= sum_slabs slab[s][tap][ci][co]
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int ntap, int CT16,
+                                                           int NT16, float* __restrict__ grad, int Cout, int Cin,
+                                                           int accumulate) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  int total = Cout * Cin * ntap;
+  if (idx >= total) return;
+  int tap = idx % ntap;
+  int ci = (idx / ntap) % Cin;
+  int co = idx / (ntap * Cin);
+  size_t stride = (size_t)ntap * CT16 * NT16;
+  const float* p = slab + ((size_t)tap * CT16 + ci) * NT16 + co;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += p[(size_t)k * stride];
+  grad[idx] = accumulate ? grad[idx] + s : s;
+}
+
+template <int KH, int KW>
+int launch_wgrad(const WgradArgs& a, int CT, int NT, int nblk, hipStream_t stream) {
+  dim3 grid(nblk), block(256);
+#define ZT_WG(ct, nt) hipLaunchKernelGGL((wgrad_mfma_f32_kernel<KH, KW, ct, nt>), grid, block, 0, stream, a); return 0
+  if (CT == 1 && NT == 3) { ZT_WG(1, 3); }
+  if (CT == 1 && NT == 4) { ZT_WG(1, 4); }
+  if (CT == 3 && NT == 3) { ZT_WG(3, 3); }
+  if (CT == 3 && NT == 1) { ZT_WG(3, 1); }
+  if (CT == 4 && NT == 4) { ZT_WG(4, 4); }
+  if (CT == 4 && NT == 1) { ZT_WG(4, 1); }
+#undef ZT_WG
+  return ZT_EINVAL;
+}
+
+// torch [Cout][Cin][KH][KW] -> device [tap][Cin'][ldw] (forward) or the data-gradient form
+// [tap'][Cout][ldw] with taps flipped and in/out channels exchanged.
+__global__ void __launch_bounds__(256) repack_w_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout,
+                                                       int Cin, int KH, int KW, int ldw, int co_off, int transpose_flip,
+                                                       int total) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int kx = idx % KW;
+  int ky = (idx / KW) % KH;
+  int ci = (idx / (KW * KH)) % Cin;
+  int co = idx / (KW * KH * Cin);
+  float v = src[idx];
+  if (!transpose_flip) dst[((size_t)(ky * KW + kx) * Cin + ci) * ldw + co_off + co] = v;
+  else dst[((size_t)((KH - 1 - ky) * KW + (KW - 1 - kx)) * Cout + co) * ldw + co_off + ci] = v;
+}
+
+}  // namespace
+
+extern "C" int zt_conv2d_nhwc_f32(const float* x, const float* x2, int csplit, int ldx, int ldx2, int N, int H, int W,
+                                  int Cin, const float* w, int ldw, const float* bias, float* y, int ldy, int out_planar,
+                                  int Cout, int KH, int KW, int stride, int padH, int padW, int act, float alpha,
+                                  const float* aux, int ldaux, int epi, hipStream_t stream) {
+  ZT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  ZT_REQUIRE(ldx % 4 == 0 && ldw % 16 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
+  ZT_REQUIRE(!x2 || (csplit % CK == 0 && ldx2 % 4 == 0 && ((uintptr_t)x2 & 15) == 0));
+  ZT_REQUIRE(epi == 0 || aux);
+  ConvArgs a;
+  a.x = x; a.x2 = x2; a.w = w; a.bias = bias; a.aux = aux; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.ldx2 = ldx2; a.csplit = csplit;
+  a.Ho = (H + 2 * padH - KH) / stride + 1;
+  a.Wo = (W + 2 * padW - KW) / stride + 1;
+  a.Cout = Cout; a.ldy = ldy; a.ldw = ldw; a.ldaux = ldaux;
+  a.padH = padH; a.padW = padW; a.act = act; a.epi = epi; a.out_planar = out_planar; a.alpha = alpha;
+  a.tilesX = zt_cdiv(a.Wo, TW);
+  a.tilesY = zt_cdiv(a.Ho, TH);
+  ZT_REQUIRE(a.Ho > 0 && a.Wo > 0);
+  int c16 = (Cout + 15) / 16;
+  int NT = c16 >= 4 ? ((c16 % 4 == 0) ? 4 : (c16 % 3 == 0 ? 3 : 4)) : c16;
+  dim3 gb((unsigned)(a.tilesX * a.tilesY * N));
+  int rc = ZT_EINVAL;
+  if (KH == 3 && KW == 3 && stride == 1) rc = launch_conv<3, 3, 1>(a, NT, gb, stream);
+  else if (KH == 3 && KW == 3 && stride == 2) rc = launch_conv<3, 3, 2>(a, NT, gb, stream);
+  else if (KH == 1 && KW == 1 && stride == 1) rc = launch_conv<1, 1, 1>(a, NT, gb, stream);
+  else if (KH == 1 && KW == 1 && stride == 2) rc = launch_conv<1, 1, 2>(a, NT, gb, stream);
+  else if (KH == 1 && KW == 5 && stride == 1) rc = launch_conv<1, 5, 1>(a, NT, gb, stream);
+  else if (KH == 5 && KW == 1 && stride == 1) rc = launch_conv<5, 1, 1>(a, NT, gb, stream);
+  else if (KH == 7 && KW == 7 && stride == 1) rc = launch_conv<7, 7, 1>(a, NT, gb, stream);
+  else if (KH == 7 && KW == 7 && stride == 2) rc = launch_conv<7, 7, 2>(a, NT, gb, stream);
+  if (rc) return rc;
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_conv2d_wgrad_nhwc_f32(const float* x, int ldx, const float* dz, int lddz, int H, int W, int Cin,
+                                        int Cout, int KH, int KW, float* slab, size_t slab_bytes, float* grad_w,
+                                        int accumulate, hipStream_t stream) {
+  ZT_REQUIRE(x && dz && slab && grad_w && ldx % 4 == 0 && lddz % 4 == 0);
+  ZT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dz & 15) == 0);
+  int CT = (Cin + 15) / 16, NT = (Cout + 15) / 16;
+  WgradArgs a;
+  a.x = x; a.dz = dz; a.slab = slab; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.Cout = Cout; a.lddz = lddz;
+  a.tilesX = zt_cdiv(W, WTW);
+  a.ntiles = a.tilesX * zt_cdiv(H, WTH);
+  size_t per = (size_t)KH * KW * CT * 16 * NT * 16 * sizeof(float);
+  int nblk = a.ntiles < 512 ? a.ntiles : 512;
+  if ((size_t)nblk * per > slab_bytes) nblk = (int)(slab_bytes / per);
+  ZT_REQUIRE(nblk >= 1);
+  int rc = ZT_EINVAL;
+  if (KH == 3 && KW == 3) rc = launch_wgrad<3, 3>(a, CT, NT, nblk, stream);
+  else if (KH == 1 && KW == 1) rc = launch_wgrad<1, 1>(a, CT, NT, nblk, stream);
+  if (rc) return rc;
+  int total = Cout * Cin * KH * KW;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(zt_cdiv(total, 256)), dim3(256), 0, stream, (const float*)slab, nblk,
+                     KH * KW, CT * 16, NT * 16, grad_w, Cout, Cin, accumulate);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_repack_conv_weight_f32(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int ldw,
+                                         int co_off, int transpose_flip, hipStream_t stream) {
+  ZT_REQUIRE(src && dst && ldw % 16 == 0);
+  int total = Cout * Cin * KH * KW;
+  hipLaunchKernelGGL(repack_w_kernel, dim3(zt_cdiv(total, 256)), dim3(256), 0, stream, src, dst, Cout, Cin, KH, KW, ldw,
+                     co_off, transpose_flip, total);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}

@@ -10,9 +10,32 @@ def _f32c(t):
     return t
 
 
+class CV:
+    """Channel view of an NHWC fp32 buffer [N,H,W,ld]: channels [off, off+C)."""
+
+    def __init__(self, t, off=0, C=None):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4
+        self.t, self.off = t, off
+        self.N, self.H, self.W, self.ld = t.shape
+        self.C = self.ld - off if C is None else C
+        assert 0 <= off and off + self.C <= self.ld
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + 4 * self.off
+
+
+def _cv(x):
+    return x if isinstance(x, CV) else CV(x)
+
+
+ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "sigmoid": 3, "tanh": 4, "sigmoid_clamp": 5}
+
+
 class Ops:
     def __init__(self, lib):
         self.lib = lib
+        self._slab = {}
 
     def _s(self, t):
         return current_stream(t.device)
@@ -114,3 +137,66 @@ class Ops:
         out = torch.empty_like(x)
         self.lib.call("zt_ycc_flat_f32", x, out, x.numel(), self._s(x))
         return out
+
+    # ---- convolution family (zt_conv.hip) ---------------------------------------------------------------------
+    def repack_weight(self, w, ldw=None, co_off=0, transpose_flip=False, out=None):
+        """torch [Cout,Cin,KH,KW] -> device layout [KH*KW, Cin', ldw]."""
+        _f32c(w)
+        Cout, Cin, KH, KW = w.shape
+        n_out, n_in = (Cin, Cout) if transpose_flip else (Cout, Cin)
+        if ldw is None:
+            ldw = (n_out + 15) // 16 * 16
+        if out is None:
+            out = torch.zeros((KH * KW, n_in, ldw), dtype=torch.float32, device=w.device)
+        self.lib.call("zt_repack_conv_weight_f32", w, out, Cout, Cin, KH, KW, ldw, co_off, int(transpose_flip), self._s(w))
+        return out
+
+    def conv2d(self, x, wdev, bias, Cout, KH, KW, stride=1, pad=(0, 0), act=None, alpha=1.0, x2=None, out=None,
+               out_planar=False, aux=None, epi=0):
+        """x: CV/tensor NHWC; optional x2 (CV) supplies channels >= x.C.  out: CV (nhwc) or planar tensor [N,Cout,Ho,Wo]."""
+        x = _cv(x)
+        Cin, csplit, ldx2, x2p = x.C, 0, 0, None
+        if x2 is not None:
+            x2 = _cv(x2)
+            csplit, Cin, ldx2, x2p = x.C, x.C + x2.C, x2.ld, x2.ptr
+        assert wdev.shape[1] == Cin and wdev.shape[0] == KH * KW, (wdev.shape, Cin, KH, KW)
+        ldw = wdev.shape[2]
+        Ho = (x.H + 2 * pad[0] - KH) // stride + 1
+        Wo = (x.W + 2 * pad[1] - KW) // stride + 1
+        dev = x.t.device
+        if out_planar:
+            if out is None:
+                out = torch.empty((x.N, Cout, Ho, Wo), dtype=torch.float32, device=dev)
+            yptr, ldy = out.data_ptr(), out.stride(1)
+        else:
+            if out is None:
+                out = torch.empty((x.N, Ho, Wo, (Cout + 3) // 4 * 4), dtype=torch.float32, device=dev)
+                if out.shape[-1] != Cout:
+                    out.zero_()
+            o = _cv(out)
+            assert (o.N, o.H, o.W) == (x.N, Ho, Wo) and o.C >= Cout
+            yptr, ldy = o.ptr, o.ld
+        auxp, ldaux = None, 0
+        if epi:
+            av = _cv(aux)
+            auxp, ldaux = av.ptr, av.ld
+        self.lib.call("zt_conv2d_nhwc_f32", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin, wdev, ldw, bias, yptr, ldy,
+                      int(out_planar), Cout, KH, KW, stride, pad[0], pad[1], ACT[act], float(alpha), auxp, ldaux, epi,
+                      self._s(x.t))
+        return out
+
+    def slab(self, dev, nbytes=96 << 20):
+        key = (dev, nbytes)
+        if key not in self._slab:
+            self._slab[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        return self._slab[key]
+
+    def conv2d_wgrad(self, x, dz, Cout, KH, KW, grad_w, accumulate=False, slab=None):
+        """grad_w [Cout,Cin,KH,KW] (+)= wgrad of a stride-1 same conv; x, dz: CV/tensor NHWC (N == 1)."""
+        x, dz = _cv(x), _cv(dz)
+        assert x.N == 1 and (x.H, x.W) == (dz.H, dz.W) and dz.C >= Cout
+        assert tuple(grad_w.shape) == (Cout, x.C, KH, KW) and grad_w.is_contiguous()
+        slab = self.slab(x.t.device) if slab is None else slab
+        self.lib.call("zt_conv2d_wgrad_nhwc_f32", x.ptr, x.ld, dz.ptr, dz.ld, x.H, x.W, x.C, Cout, KH, KW, slab,
+                      slab.numel() * 4, grad_w, int(accumulate), self._s(x.t))
+        return grad_w
