@@ -69,6 +69,30 @@ int zt_conv2d_wgrad_nhwc_f32(const float* x, int ldx, const float* dz, int lddz,
 int zt_repack_conv_weight_f32(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int ldw, int co_off,
                               int transpose_flip, zt_stream_t stream);
 
+
+/* ---- normalisation (zt_norm.hip): nn.BatchNorm2d of model.py:62 (train mode, shared 3x), eval BatchNorm /
+ * InstanceNorm of model/RAFT/extractor.py:117-191.  All on nhwc buffers, C % 4 == 0. ------------------------------- */
+/* per-(n,c) partial sums over HW pixels: partial[((n*nblk+blk)*2 + {0 sum, 1 sum of squares})*C + c] */
+int zt_chan_stats_nhwc_f32(const float* x, int ldx, int N, int HW, int C, int nblk, float* partial, zt_stream_t stream);
+/* mode 0 instance norm (scale = rstd, shift = -mean*rstd); 1 train BN (batch stats, running stats += momentum update with
+ * unbiased variance, *num_batches_tracked += 1); 2 eval BN (running stats).  Outputs scale/shift (and mean/rstd) [N][C]. */
+int zt_norm_finalize_f32(const float* partial, int nblk, int N, int C, long long count, float eps, int mode,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         long long* num_batches_tracked, float momentum, float* scale, float* shift, float* mean_out,
+                         float* rstd_out, zt_stream_t stream);
+/* y = [outer_relu]([res +] [inner_relu](x*scale + shift)) */
+int zt_norm_apply_nhwc_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldres,
+                           float* y, int ldy, int N, int HW, int C, int inner_relu, int outer_relu, zt_stream_t stream);
+/* backward of y = ReLU(BN_train(z)): stage 1 partial sums of dyh = dy*[bn>0] and dyh*zhat; generic partial reduction;
+ * stage 2 dz = gamma*rstd*(dyh - mean(dyh) - zhat*mean(dyh*zhat)) with sums = [sum dyh (C) | sum dyh*zhat (C)] */
+int zt_bn_bwd_reduce_f32(const float* dy, int lddy, const float* z, int ldz, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, int HW, int C, int nblk, float* partial, zt_stream_t stream);
+int zt_partial_reduce_f32(const float* partial, int nblk, int stride, int n, float* out, int accumulate, float* out2,
+                          zt_stream_t stream);
+int zt_bn_bwd_apply_f32(const float* dy, int lddy, const float* z, int ldz, const float* scale, const float* shift,
+                        const float* mean, const float* rstd, const float* sums, float* dz, int lddz, int HW, int C,
+                        zt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

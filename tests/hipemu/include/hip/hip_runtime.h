@@ -15,6 +15,9 @@
 #include <cstring>
 #include <functional>
 #include <vector>
+#include <algorithm>
+using std::min;
+using std::max;
 
 #define __global__
 #define __device__

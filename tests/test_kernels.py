@@ -187,3 +187,49 @@ def test_conv_wgrad(backend, case):
     assert maxerr(gw, w.grad) < 5e-5, maxerr(gw, w.grad)
     ops.conv2d_wgrad(xd, dzd, Cout, K, K, gw, accumulate=True)
     assert maxerr(gw, 2 * w.grad) < 1e-4
+
+
+def test_norms(backend):
+    import torch.nn.functional as F
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    g = torch.Generator().manual_seed(11)
+    # instance norm on a batch of 2 (RAFT fnet) with relu, then residual form
+    x = torch.randn(2, 96, 9, 14, generator=g) * 2 + 0.7
+    res = torch.randn(2, 96, 9, 14, generator=g)
+    xd, rd = _nhwc(x).to(dev), _nhwc(res).to(dev)
+    part = ops.chan_stats(xd, nblk=3)
+    sc, sh, _, _ = ops.norm_finalize(part, 2, 96, 9 * 14, 0)
+    y = ops.norm_apply(xd, sc, sh, inner_relu=True)
+    assert maxerr(y.cpu().permute(0, 3, 1, 2), F.relu(F.instance_norm(x))) < 2e-5
+    y = ops.norm_apply(xd, sc, sh, res=rd, inner_relu=True, outer_relu=True)
+    assert maxerr(y.cpu().permute(0, 3, 1, 2), F.relu(res + F.relu(F.instance_norm(x)))) < 2e-5
+    # eval BN
+    C = 64
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    xb = torch.randn(1, C, 10, 13, generator=g)
+    sc, sh, _, _ = ops.norm_finalize(None, 1, C, 1, 2, gam.to(dev), bet.to(dev), rm.to(dev), rv.to(dev), dev=dev)
+    y = ops.norm_apply(_nhwc(xb).to(dev), sc, sh)
+    assert maxerr(y.cpu().permute(0, 3, 1, 2), F.batch_norm(xb, rm, rv, gam, bet, False, 0.1, 1e-5)) < 1e-5
+    # train BN + ReLU + residual: forward, running stats, backward (Enhancer block)
+    f = torch.randn(1, C, 10, 13, generator=g)
+    z = (torch.randn(1, C, 10, 13, generator=g) * 1.7 + 0.3).requires_grad_(True)
+    gam_t, bet_t = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    rm_t, rv_t = rm.clone(), rv.clone()
+    out_ref = f + F.relu(F.batch_norm(z, rm_t, rv_t, gam_t, bet_t, True, 0.1, 1e-5))
+    dy = torch.randn(1, C, 10, 13, generator=g)
+    (out_ref * dy).sum().backward()
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    zd = _nhwc(z.detach()).to(dev)
+    part = ops.chan_stats(zd)
+    sc, sh, mu, rs = ops.norm_finalize(part, 1, C, 130, 1, gam.to(dev), bet.to(dev), rmd, rvd, nbt)
+    y = ops.norm_apply(zd, sc, sh, res=_nhwc(f).to(dev), inner_relu=True)
+    assert maxerr(y.cpu().permute(0, 3, 1, 2), out_ref) < 1e-5
+    assert maxerr(rmd, rm_t) < 1e-6 and maxerr(rvd, rv_t) < 1e-6 and int(nbt) == 1
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dz = ops.bn_relu_bwd(_nhwc(dy).to(dev), zd, sc, sh, mu, rs, dg, db)
+    assert maxerr(dz.cpu().permute(0, 3, 1, 2), z.grad) < 2e-5
+    assert maxerr(dg, gam_t.grad) < 2e-4 and maxerr(db, bet_t.grad) < 2e-4

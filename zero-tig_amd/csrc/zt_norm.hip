@@ -1,0 +1,260 @@
+// Per-channel statistics + normalisation on NHWC fp32 activations:
+//   train-mode BatchNorm of the Enhancer's shared block (reference model.py:60-67; torch BatchNorm2d semantics:
+//   biased batch variance for normalisation, unbiased for running_var, momentum 0.1) incl. its backward,
+//   eval-mode BatchNorm of RAFT's context encoder and InstanceNorm of its feature encoder (extractor.py:117-191).
+// Two-stage reductions (per-workgroup fp32 partials, fp64 combine) -> deterministic, no atomics.
+#include "zt_common.h"
+
+namespace {
+
+// partial[((n*nblk + blk)*2 + {0:sum,1:sumsq})*C + c]
+__global__ void __launch_bounds__(256) chan_stats_kernel(const float* __restrict__ x, int ldx, int HW, int C, int nblk,
+                                                         float* __restrict__ partial) {
+  __shared__ float4 sh_s[256];
+  __shared__ float4 sh_q[256];
+  const int Q = C >> 2, R = 256 / Q;
+  const int tid = threadIdx.x;
+  const int row = tid / Q, q = tid - row * Q;
+  const int n = blockIdx.y, blk = blockIdx.x;
+  const int chunk = (HW + nblk - 1) / nblk;
+  const int p0 = blk * chunk, p1 = min(HW, p0 + chunk);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = s;
+  if (row < R) {
+    const float* base = x + (size_t)n * HW * ldx + q * 4;
+    for (int p = p0 + row; p < p1; p += R) {
+      float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * ldx);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
+    }
+  }
+  sh_s[tid] = s;
+  sh_q[tid] = ss;
+  __syncthreads();
+  if (row == 0) {
+    for (int r = 1; r < R; ++r) {
+      float4 a = sh_s[r * Q + q], b = sh_q[r * Q + q];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      ss.x += b.x; ss.y += b.y; ss.z += b.z; ss.w += b.w;
+    }
+    float* o = partial + ((size_t)(n * nblk + blk) * 2) * C + q * 4;
+    *reinterpret_cast<float4*>(o) = s;
+    *reinterpret_cast<float4*>(o + C) = ss;
+  }
+}
+
+// mode 0: instance norm (per n,c; no affine)   mode 1: train BN (N must be 1; updates running stats)   mode 2: eval BN
+__global__ void __launch_bounds__(256) norm_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                            double count, float eps, int mode,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                            long long* __restrict__ nbt, float momentum,
+                                                            float* __restrict__ scale, float* __restrict__ shift,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float mean, rstd;
+    if (mode == 2) {
+      mean = running_mean[c];
+      rstd = 1.f / sqrtf(running_var[c] + eps);
+    } else {
+      double s = 0.0, q = 0.0;
+      for (int b = 0; b < nblk; ++b) {
+        const float* p = partial + ((size_t)(n * nblk + b) * 2) * C;
+        s += (double)p[c];
+        q += (double)p[C + c];
+      }
+      double m = s / count;
+      double var = q / count - m * m;
+      if (var < 0.0) var = 0.0;
+      mean = (float)m;
+      rstd = (float)(1.0 / sqrt(var + (double)eps));
+      if (mode == 1) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        float unbiased = (float)(var * count / (count - 1.0));
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
+    }
+    float g = (mode == 0) ? 1.f : gamma[c];
+    float b = (mode == 0) ? 0.f : beta[c];
+    float sc = g * rstd;
+    scale[n * C + c] = sc;
+    shift[n * C + c] = b - mean * sc;
+    if (mean_out) mean_out[n * C + c] = mean;
+    if (rstd_out) rstd_out[n * C + c] = rstd;
+  }
+  if (mode == 1 && nbt && threadIdx.x == 0 && blockIdx.x == 0) *nbt += 1;
+}
+
+// y = [outer_relu]( [res +] [inner_relu](x*scale + shift) )
+__global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ res, int ldres, float* __restrict__ y,
+                                                         int ldy, int HW, int C, int inner_relu, int outer_relu,
+                                                         long long total4) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int Q = C >> 2;
+  int q = (int)(i % Q);
+  long long p = i / Q;            // global pixel index over N*HW
+  int n = (int)(p / HW);
+  float4 v = *reinterpret_cast<const float4*>(x + p * ldx + q * 4);
+  float4 sc = *reinterpret_cast<const float4*>(scale + n * C + q * 4);
+  float4 sf = *reinterpret_cast<const float4*>(shift + n * C + q * 4);
+  v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+  if (inner_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  if (res) {
+    float4 r = *reinterpret_cast<const float4*>(res + p * ldres + q * 4);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  if (outer_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  *reinterpret_cast<float4*>(y + p * ldy + q * 4) = v;
+}
+
+// BN(+ReLU) backward, stage 1: partial[(blk*2 + {0: sum dyh, 1: sum dyh*zhat})*C + c], dyh = dy * [x*scale+shift > 0]
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy,
+                                                            const float* __restrict__ z, int ldz,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            int HW, int C, int nblk, float* __restrict__ partial) {
+  __shared__ float4 sh_a[256];
+  __shared__ float4 sh_b[256];
+  const int Q = C >> 2, R = 256 / Q;
+  const int tid = threadIdx.x;
+  const int row = tid / Q, q = tid - row * Q;
+  const int blk = blockIdx.x;
+  const int chunk = (HW + nblk - 1) / nblk;
+  const int p0 = blk * chunk, p1 = min(HW, p0 + chunk);
+  float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+  if (row < R) {
+    float4 sc = *reinterpret_cast<const float4*>(scale + q * 4), sf = *reinterpret_cast<const float4*>(shift + q * 4);
+    float4 mu = *reinterpret_cast<const float4*>(mean + q * 4), rs = *reinterpret_cast<const float4*>(rstd + q * 4);
+    for (int p = p0 + row; p < p1; p += R) {
+      float4 g = *reinterpret_cast<const float4*>(dy + (size_t)p * lddy + q * 4);
+      float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * ldz + q * 4);
+      float gx = (v.x * sc.x + sf.x > 0.f) ? g.x : 0.f, gy = (v.y * sc.y + sf.y > 0.f) ? g.y : 0.f;
+      float gz = (v.z * sc.z + sf.z > 0.f) ? g.z : 0.f, gw = (v.w * sc.w + sf.w > 0.f) ? g.w : 0.f;
+      sa.x += gx; sa.y += gy; sa.z += gz; sa.w += gw;
+      sb.x += gx * ((v.x - mu.x) * rs.x); sb.y += gy * ((v.y - mu.y) * rs.y);
+      sb.z += gz * ((v.z - mu.z) * rs.z); sb.w += gw * ((v.w - mu.w) * rs.w);
+    }
+  }
+  sh_a[tid] = sa;
+  sh_b[tid] = sb;
+  __syncthreads();
+  if (row == 0) {
+    for (int r = 1; r < R; ++r) {
+      float4 a = sh_a[r * Q + q], b = sh_b[r * Q + q];
+      sa.x += a.x; sa.y += a.y; sa.z += a.z; sa.w += a.w;
+      sb.x += b.x; sb.y += b.y; sb.z += b.z; sb.w += b.w;
+    }
+    float* o = partial + ((size_t)blk * 2) * C + q * 4;
+    *reinterpret_cast<float4*>(o) = sa;
+    *reinterpret_cast<float4*>(o + C) = sb;
+  }
+}
+
+// out[j] (+)= sum_b partial[b*stride + j]   (fp64 combine); optional second destination without accumulation
+__global__ void __launch_bounds__(256) partial_reduce_kernel(const float* __restrict__ partial, int nblk, int stride, int n,
+                                                             float* __restrict__ out, int accumulate,
+                                                             float* __restrict__ out2) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * stride + j];
+  float v = (float)s;
+  if (out) out[j] = accumulate ? out[j] + v : v;
+  if (out2) out2[j] = v;
+}
+
+// dz = gamma*rstd * (dyh - sum_dyh/n - zhat * sum_dyh_zhat/n)
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ z,
+                                                           int ldz, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ sums,
+                                                           float inv_n, float* __restrict__ dz, int lddz, int C,
+                                                           long long total4) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int Q = C >> 2;
+  int q = (int)(i % Q);
+  long long p = i / Q;
+  float4 g = *reinterpret_cast<const float4*>(dy + p * lddy + q * 4);
+  float4 v = *reinterpret_cast<const float4*>(z + p * ldz + q * 4);
+  float4 sc = *reinterpret_cast<const float4*>(scale + q * 4), sf = *reinterpret_cast<const float4*>(shift + q * 4);
+  float4 mu = *reinterpret_cast<const float4*>(mean + q * 4), rs = *reinterpret_cast<const float4*>(rstd + q * 4);
+  float4 s1 = *reinterpret_cast<const float4*>(sums + q * 4), s2 = *reinterpret_cast<const float4*>(sums + C + q * 4);
+  float4 o;
+#define ZT_BN1(f)                                             \
+  {                                                           \
+    float gg = (v.f * sc.f + sf.f > 0.f) ? g.f : 0.f;         \
+    float zh = (v.f - mu.f) * rs.f;                           \
+    o.f = sc.f * (gg - s1.f * inv_n - zh * (s2.f * inv_n));   \
+  }
+  ZT_BN1(x) ZT_BN1(y) ZT_BN1(z) ZT_BN1(w)
+#undef ZT_BN1
+  *reinterpret_cast<float4*>(dz + p * lddz + q * 4) = o;
+}
+
+}  // namespace
+
+extern "C" int zt_chan_stats_nhwc_f32(const float* x, int ldx, int N, int HW, int C, int nblk, float* partial,
+                                      hipStream_t stream) {
+  ZT_REQUIRE(x && partial && C % 4 == 0 && C >= 4 && C <= 1024 && ldx % 4 == 0 && nblk > 0 && ((uintptr_t)x & 15) == 0);
+  hipLaunchKernelGGL(chan_stats_kernel, dim3(nblk, N), dim3(256), 0, stream, x, ldx, HW, C, nblk, partial);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_norm_finalize_f32(const float* partial, int nblk, int N, int C, long long count, float eps, int mode,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    long long* num_batches_tracked, float momentum, float* scale, float* shift,
+                                    float* mean_out, float* rstd_out, hipStream_t stream) {
+  ZT_REQUIRE(scale && shift && (mode == 2 || partial) && (mode == 0 || (gamma && beta)));
+  ZT_REQUIRE(mode == 0 || (running_mean && running_var));
+  ZT_REQUIRE(mode != 1 || N == 1);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(N), dim3(256), 0, stream, partial, nblk, C, (double)count, eps, mode, gamma,
+                     beta, running_mean, running_var, num_batches_tracked, momentum, scale, shift, mean_out, rstd_out);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_norm_apply_nhwc_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res,
+                                      int ldres, float* y, int ldy, int N, int HW, int C, int inner_relu, int outer_relu,
+                                      hipStream_t stream) {
+  ZT_REQUIRE(x && y && scale && shift && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!res || ldres % 4 == 0));
+  long long total4 = (long long)N * HW * (C / 4);
+  hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, x, ldx, scale, shift,
+                     res, ldres, y, ldy, HW, C, inner_relu, outer_relu, total4);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_bn_bwd_reduce_f32(const float* dy, int lddy, const float* z, int ldz, const float* scale,
+                                    const float* shift, const float* mean, const float* rstd, int HW, int C, int nblk,
+                                    float* partial, hipStream_t stream) {
+  ZT_REQUIRE(dy && z && partial && C % 4 == 0 && C <= 1024);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, stream, dy, lddy, z, ldz, scale, shift, mean, rstd, HW,
+                     C, nblk, partial);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_partial_reduce_f32(const float* partial, int nblk, int stride, int n, float* out, int accumulate,
+                                     float* out2, hipStream_t stream) {
+  ZT_REQUIRE(partial && n > 0 && (out || out2));
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(zt_cdiv(n, 256)), dim3(256), 0, stream, partial, nblk, stride, n, out,
+                     accumulate, out2);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_bn_bwd_apply_f32(const float* dy, int lddy, const float* z, int ldz, const float* scale,
+                                   const float* shift, const float* mean, const float* rstd, const float* sums,
+                                   float* dz, int lddz, int HW, int C, hipStream_t stream) {
+  ZT_REQUIRE(dy && z && dz && sums && C % 4 == 0);
+  long long total4 = (long long)HW * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, dy, lddy, z, ldz,
+                     scale, shift, mean, rstd, sums, 1.f / (float)HW, dz, lddz, C, total4);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}

@@ -200,3 +200,56 @@ class Ops:
         self.lib.call("zt_conv2d_wgrad_nhwc_f32", x.ptr, x.ld, dz.ptr, dz.ld, x.H, x.W, x.C, Cout, KH, KW, slab,
                       slab.numel() * 4, grad_w, int(accumulate), self._s(x.t))
         return grad_w
+
+    # ---- normalisation (zt_norm.hip) --------------------------------------------------------------------------
+    def _nblk(self, HW):
+        return max(1, min(1024, HW // 64))
+
+    def chan_stats(self, x, nblk=None):
+        """-> partial [N, nblk, 2, C] (sum, sum of squares) for a CV/tensor NHWC."""
+        x = _cv(x)
+        HW = x.H * x.W
+        nblk = self._nblk(HW) if nblk is None else nblk
+        part = torch.empty((x.N, nblk, 2, x.C), dtype=torch.float32, device=x.t.device)
+        self.lib.call("zt_chan_stats_nhwc_f32", x.ptr, x.ld, x.N, HW, x.C, nblk, part, self._s(x.t))
+        return part
+
+    def norm_finalize(self, part, N, C, count, mode, gamma=None, beta=None, rm=None, rv=None, nbt=None, momentum=0.1,
+                      eps=1e-5, dev=None):
+        dev = part.device if part is not None else dev
+        scale = torch.empty((N, C), dtype=torch.float32, device=dev)
+        shift, mean, rstd = torch.empty_like(scale), torch.empty_like(scale), torch.empty_like(scale)
+        nblk = part.shape[1] if part is not None else 0
+        self.lib.call("zt_norm_finalize_f32", part, nblk, N, C, count, eps, mode, gamma, beta, rm, rv, nbt, momentum,
+                      scale, shift, mean, rstd, current_stream(dev))
+        return scale, shift, mean, rstd
+
+    def norm_apply(self, x, scale, shift, out=None, res=None, inner_relu=False, outer_relu=False):
+        x = _cv(x)
+        if out is None:
+            out = torch.empty((x.N, x.H, x.W, x.C), dtype=torch.float32, device=x.t.device)
+        o = _cv(out)
+        rp, ldr = (None, 0) if res is None else (_cv(res).ptr, _cv(res).ld)
+        self.lib.call("zt_norm_apply_nhwc_f32", x.ptr, x.ld, scale, shift, rp, ldr, o.ptr, o.ld, x.N, x.H * x.W, x.C,
+                      int(inner_relu), int(outer_relu), self._s(x.t))
+        return out
+
+    def partial_reduce(self, part, nblk, stride, n, out=None, accumulate=False, out2=None):
+        self.lib.call("zt_partial_reduce_f32", part, nblk, stride, n, out, int(accumulate), out2, self._s(part))
+
+    def bn_relu_bwd(self, dy, z, scale, shift, mean, rstd, dgamma, dbeta, out=None):
+        """backward of ReLU(BN_train(z)) for N == 1; accumulates dgamma/dbeta; returns dz (NHWC)."""
+        dy, z = _cv(dy), _cv(z)
+        HW, C = z.H * z.W, z.C
+        nblk = self._nblk(HW)
+        part = torch.empty((nblk, 2, C), dtype=torch.float32, device=z.t.device)
+        self.lib.call("zt_bn_bwd_reduce_f32", dy.ptr, dy.ld, z.ptr, z.ld, scale, shift, mean, rstd, HW, C, nblk, part, self._s(z.t))
+        sums = torch.empty((2, C), dtype=torch.float32, device=z.t.device)
+        self.partial_reduce(part, nblk, 2 * C, 2 * C, out=None, out2=sums)
+        self.partial_reduce(part, nblk, 2 * C, C, out=dbeta, accumulate=True)
+        self.lib.call("zt_partial_reduce_f32", part.data_ptr() + 4 * C, nblk, 2 * C, C, dgamma, 1, None, self._s(z.t))
+        if out is None:
+            out = torch.empty((1, z.H, z.W, C), dtype=torch.float32, device=z.t.device)
+        o = _cv(out)
+        self.lib.call("zt_bn_bwd_apply_f32", dy.ptr, dy.ld, z.ptr, z.ld, scale, shift, mean, rstd, sums, o.ptr, o.ld, HW, C, self._s(z.t))
+        return out
