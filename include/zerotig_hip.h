@@ -93,6 +93,52 @@ int zt_bn_bwd_apply_f32(const float* dy, int lddy, const float* z, int ldz, cons
                         const float* mean, const float* rstd, const float* sums, float* dz, int lddz, int HW, int C,
                         zt_stream_t stream);
 
+
+/* ---- element-wise stages of Network.forward (model.py:144-203) and their backward (zt_glue.hip); planar [3][H][W], H,W even */
+/* model.py:145-148, loss.py:25,51: x = inp+1e-4; (L11,L12) = pair_downsampler(x); (Lq11,Lq12) = pair_downsampler(inp+1e-9) */
+int zt_prep_input_f32(const float* inp, float* x, float* L11, float* L12, float* Lq11, float* Lq12, int H, int W, zt_stream_t stream);
+/* torch.cat([...],1) of up to four planar tensors into one nhwc buffer (remaining channels zero) (model.py:168,179,184,189) */
+int zt_pack_nhwc_f32(float* dst, int ld, long long HW, const float* s0, int c0, const float* s1, int c1, const float* s2, int c2,
+                     const float* s3, int c3, zt_stream_t stream);
+/* model.py:149-152 + loss.py:54: L2 = clamp(x-n,1e-4,1); L_pred1/2 = L11/12 - n11/12; (den1,den2) = pair_downsampler(L2) */
+int zt_d1_tail_f32(const float* x, const float* n, const float* L11, const float* n11, const float* L12, const float* n12,
+                   float* L2, float* Lp1, float* Lp2, float* den1, float* den2, int H, int W, zt_stream_t stream);
+/* model.py:169-177,198-199 */
+int zt_post_enh_f32(const float* x, const float* s2, const float* L2, const float* L11, const float* L12, float* s21, float* s22,
+                    float* H2, float* H11, float* H12, float* H1, int H, int W, zt_stream_t stream);
+/* model.py:179-192: (outA|outB) = clamp(cat[A,B] - r, 1e-4, 1), r planar 6ch */
+int zt_clamp_sub6_f32(const float* A, const float* B, const float* r, float* outA, float* outB, long long HW, zt_stream_t stream);
+/* its backward into the nhwc gradient of r */
+int zt_clamp_sub6_bwd_f32(const float* A, const float* B, const float* r, const float* gA, const float* gB, float* dr, int ld,
+                          long long HW, zt_stream_t stream);
+/* all gradient paths into s2 (H2, H11/H12, pair_downsampler, Denoise_2 inputs, direct loss terms) -> Enhancer output-layer gradient (nhwc) */
+int zt_post_enh_bwd_f32(const float* x, const float* s2, const float* L11, const float* L12, const float* s21, const float* s22,
+                        const float* dIn5, const float* dH2x, const float* dIn3, const float* dIn4, const float* ds2_direct,
+                        float* dO, int ld, float* ds2_total, int H, int W, zt_stream_t stream);
+/* gradients entering the three Denoise_1 invocations (nhwc) */
+int zt_d1_bwd_prep_f32(const float* x, const float* n, const float* dLp1, const float* dLp2, const float* dden1,
+                       const float* dden2, float* dn, float* dn11, float* dn12, int ld, int H, int W, zt_stream_t stream);
+/* ReLU backward on nhwc buffers: out = g * [a > 0] */
+int zt_relu_mask_nhwc_f32(const float* g, int ldg, const float* a, int lda, float* out, int ldo, long long npix, int C, zt_stream_t stream);
+int zt_add3_f32(const float* a, const float* b, const float* c, float* out, long long n, zt_stream_t stream);
+
+/* ---- LossFunction.forward (loss.py:12-78) + gradient w.r.t. its inputs (zt_loss.hip) ------------------------------- */
+int zt_plane_sums_f32(const float* x, int C, long long HW, int nblk, float* partial, zt_stream_t stream);
+/* loss.py:26-37: scal[0..2] = clamp(enhancement_factor,1,25), scal[3..5] = 0.7^-ef / ef */
+int zt_loss_scalars_f32(const float* partial, int nblk, long long HW, int is_WB, float* scal, zt_stream_t stream);
+/* loss.py:46-49 (700 MSE, 1000 MSE, 5 SmoothLoss, 1600 L_TV): partial[block][4] + direct d/ds2 */
+int zt_loss_s2_f32(const float* L2, const float* s2, const float* Y, const float* scal, int H, int W, float* ds2, float* partial,
+                   zt_stream_t stream);
+/* loss.py:51-62, 68-73: partial[block][10] = res1_a..d, res2_a..d, inter_a, inter_b; direct gradients; u1/u2 = (1-m)*de (to be LocalMean-adjointed) */
+int zt_loss_half_f32(const float* Lq11, const float* Lq12, const float* Lp1, const float* Lp2, const float* den1, const float* den2,
+                     const float* H3p, const float* H4p, const float* H11, const float* s21, const float* H12, const float* s22,
+                     const float* H3d1, const float* H3d2, const float* mask, const float* LM1, const float* LM2, float* dLp1,
+                     float* dLp2, float* dden1, float* dden2, float* dH3p, float* dH4p, float* dH3d1, float* dH3d2, float* u1,
+                     float* u2, long long hw, float* partial, zt_stream_t stream);
+/* loss.py:64, 66, 75-77: partial[block][3] = color, ill, var; dH3_blur, ds3, gV = d/dV(H2) (= -d/dV(H3-H2)) */
+int zt_loss_full_f32(const float* H2b, const float* H3b, const float* s2, const float* s3, const float* VH2, const float* VN,
+                     float* dH3b, float* ds3, float* gV, long long n, float* partial, zt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

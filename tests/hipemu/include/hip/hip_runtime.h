@@ -25,6 +25,7 @@ using std::max;
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __launch_bounds__(...)
+#define __constant__ static const
 #define __restrict__ __restrict
 
 struct dim3 {

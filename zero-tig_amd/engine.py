@@ -1,0 +1,272 @@
+"""Static execution plan of the Zero-TIG hot path over the HIP kernels.
+
+`Engine.forward()`     = Network.forward            (reference model/model.py:144-203)
+`Engine.loss_grads()`  = LossFunction.forward       (loss.py:23-78) fused with its gradient, then the hand-derived
+                         backward through Denoise_2 / Enhancer / Denoise_1 (what autograd does at train.py:129)
+All compute is in libzerotig_hip.so; torch only owns the buffers.  The graph is static, so the backward pass is written
+out explicitly instead of being recorded by autograd: activations needed later are kept in `self.sv`.
+"""
+import torch
+
+from .ops import CV
+
+TERM_NAMES = ["enh_s2", "enh_norm", "smooth", "tv", "res1_a", "res1_b", "res1_c", "res1_d", "res2_a", "res2_b", "res2_c",
+              "res2_d", "color", "ill", "inter_a", "inter_b", "var"]
+
+D1 = "denoise_1"
+D2 = "denoise_2"
+
+
+class Engine:
+    def __init__(self, ops, params, buffers, is_WB=False, device=None):
+        """params: {name: tensor} of the 20 trainable tensors (torch layout, on device); buffers: BN running stats."""
+        self.ops, self.lib = ops, ops.lib
+        self.p, self.buf = params, buffers
+        self.is_WB = is_WB
+        self.dev = device if device is not None else next(iter(params.values())).device
+        self.sv = {}
+        self.wd = {}
+        self.training = True
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _new(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def _zeros(self, *shape):
+        return torch.zeros(shape, dtype=torch.float32, device=self.dev)
+
+    def _stream(self):
+        from .lib import current_stream
+        return current_stream(self.dev)
+
+    def repack_weights(self):
+        """torch-layout parameters -> device conv layouts (forward and data-gradient operators)."""
+        o, p, wd = self.ops, self.p, self.wd
+        for pre in (D1 + ".conv1", D1 + ".conv2", D1 + ".conv3", D2 + ".conv1", D2 + ".conv2", D2 + ".conv3",
+                    "enhance.in_conv.0", "enhance.conv.0", "enhance.out_conv.0"):
+            w = p[pre + ".weight"]
+            wd[pre] = o.repack_weight(w, out=wd.get(pre))
+            if pre not in (D1 + ".conv1", "enhance.in_conv.0"):        # inputs of these need no gradient
+                wd[pre + "/T"] = o.repack_weight(w, transpose_flip=True, out=wd.get(pre + "/T"))
+
+    def _pack(self, ld, HW, srcs, H, W):
+        dst = self._new(1, H, W, ld)
+        a = []
+        for t in srcs:
+            a += [t, t.shape[1]]
+        while len(a) < 8:
+            a += [None, 0]
+        self.lib.call("zt_pack_nhwc_f32", dst, ld, HW, *a, self._stream())
+        return dst
+
+    # ------------------------------------------------------------------------------------------------ denoisers
+    def _denoise_fwd(self, pre, srcs, H, W, cin, cout, key):
+        """conv3x3+LReLU, conv3x3+LReLU, conv1x1 on cat(srcs) (model.py:15-44). Returns planar [1,cout,H,W]."""
+        o, p, wd = self.ops, self.p, self.wd
+        ld = (cin + 3) // 4 * 4
+        u = self._pack(ld, H * W, srcs, H, W)
+        a1 = o.conv2d(CV(u, 0, cin), wd[pre + ".conv1"], p[pre + ".conv1.bias"], 48, 3, 3, 1, (1, 1), "lrelu")
+        a2 = o.conv2d(a1, wd[pre + ".conv2"], p[pre + ".conv2.bias"], 48, 3, 3, 1, (1, 1), "lrelu")
+        r = o.conv2d(a2, wd[pre + ".conv3"], p[pre + ".conv3.bias"], cout, 1, 1, 1, (0, 0), None, out_planar=True)
+        if self.keep:
+            self.sv[key] = (u, a1, a2, cin)
+        return r
+
+    def _bias_grad(self, dz, cout, name):
+        o = self.ops
+        part = o.chan_stats(dz)
+        nblk, C = part.shape[1], part.shape[3]
+        o.partial_reduce(part, nblk, 2 * C, cout, out=self.g[name], accumulate=True)
+
+    def _denoise_bwd(self, pre, key, dr, cout, want_input_grad):
+        """dr: NHWC gradient of the 1x1 output (first `cout` channels valid).  Accumulates parameter grads; returns the planar
+        [1,cin,H,W] gradient of the packed input when requested."""
+        o, wd, g = self.ops, self.wd, self.g
+        u, a1, a2, cin = self.sv[key]
+        H, W = a1.shape[1], a1.shape[2]
+        drv = CV(dr, 0, cout)
+        o.conv2d_wgrad(a2, drv, cout, 1, 1, g[pre + ".conv3.weight"], accumulate=True)
+        self._bias_grad(dr, cout, pre + ".conv3.bias")
+        dz2 = o.conv2d(drv, wd[pre + ".conv3/T"], None, 48, 1, 1, 1, (0, 0), None, aux=a2, epi=1)
+        o.conv2d_wgrad(a1, dz2, 48, 3, 3, g[pre + ".conv2.weight"], accumulate=True)
+        self._bias_grad(dz2, 48, pre + ".conv2.bias")
+        dz1 = o.conv2d(dz2, wd[pre + ".conv2/T"], None, 48, 3, 3, 1, (1, 1), None, aux=a1, epi=1)
+        o.conv2d_wgrad(CV(u, 0, cin), dz1, 48, 3, 3, g[pre + ".conv1.weight"], accumulate=True)
+        self._bias_grad(dz1, 48, pre + ".conv1.bias")
+        if want_input_grad:
+            return o.conv2d(dz1, wd[pre + ".conv1/T"], None, cin, 3, 3, 1, (1, 1), None, out_planar=True)
+        return None
+
+    # ------------------------------------------------------------------------------------------------ enhancer
+    def _enhancer_fwd(self, wpH, wps, L2, H, W):
+        """model.py:47-81."""
+        o, p, wd, b = self.ops, self.p, self.wd, self.buf
+        u = self._pack(12, H * W, [wpH, wps, L2], H, W)
+        f = o.conv2d(CV(u, 0, 9), wd["enhance.in_conv.0"], p["enhance.in_conv.0.bias"], 64, 3, 3, 1, (1, 1), "relu")
+        feats, zs, stats = [f], [], []
+        for _ in range(3):
+            z = o.conv2d(f, wd["enhance.conv.0"], p["enhance.conv.0.bias"], 64, 3, 3, 1, (1, 1), None)
+            if self.training:
+                part = o.chan_stats(z)
+                st = o.norm_finalize(part, 1, 64, H * W, 1, p["enhance.conv.1.weight"], p["enhance.conv.1.bias"],
+                                     b["enhance.conv.1.running_mean"], b["enhance.conv.1.running_var"],
+                                     b["enhance.conv.1.num_batches_tracked"], 0.1)
+            else:
+                st = o.norm_finalize(None, 1, 64, 1, 2, p["enhance.conv.1.weight"], p["enhance.conv.1.bias"],
+                                     b["enhance.conv.1.running_mean"], b["enhance.conv.1.running_var"], dev=self.dev)
+            f = o.norm_apply(z, st[0], st[1], res=f, inner_relu=True)
+            feats.append(f)
+            zs.append(z)
+            stats.append(st)
+        s2 = o.conv2d(f, wd["enhance.out_conv.0"], p["enhance.out_conv.0.bias"], 3, 3, 3, 1, (1, 1), "sigmoid_clamp", out_planar=True)
+        if self.keep:
+            self.sv["E"] = (u, feats, zs, stats)
+        return s2
+
+    def _enhancer_bwd(self, dO):
+        """dO: NHWC4 gradient w.r.t. the out_conv pre-activation."""
+        o, wd, g, p = self.ops, self.wd, self.g, self.p
+        u, feats, zs, stats = self.sv["E"]
+        H, W = feats[0].shape[1], feats[0].shape[2]
+        dOv = CV(dO, 0, 3)
+        o.conv2d_wgrad(feats[3], dOv, 3, 3, 3, g["enhance.out_conv.0.weight"], accumulate=True)
+        self._bias_grad(dO, 3, "enhance.out_conv.0.bias")
+        df = o.conv2d(dOv, wd["enhance.out_conv.0/T"], None, 64, 3, 3, 1, (1, 1), None)
+        for i in (2, 1, 0):
+            sc, sh, mu, rs = stats[i]
+            if not self.training:
+                raise NotImplementedError("backward through eval-mode BatchNorm (reference train.py:138 quirk) is not built yet")
+            dz = o.bn_relu_bwd(df, zs[i], sc, sh, mu, rs, g["enhance.conv.1.weight"], g["enhance.conv.1.bias"])
+            o.conv2d_wgrad(feats[i], dz, 64, 3, 3, g["enhance.conv.0.weight"], accumulate=True)
+            self._bias_grad(dz, 64, "enhance.conv.0.bias")
+            df = o.conv2d(dz, wd["enhance.conv.0/T"], None, 64, 3, 3, 1, (1, 1), None, aux=df, epi=3)
+        # through the in_conv ReLU: mask by the saved activation (epi 2 of a 1x1 identity is overkill -> dedicated op)
+        dz0 = self._new(1, H, W, 64)
+        self.lib.call("zt_relu_mask_nhwc_f32", df, 64, feats[0], 64, dz0, 64, H * W, 64, self._stream())
+        o.conv2d_wgrad(CV(u, 0, 9), dz0, 64, 3, 3, g["enhance.in_conv.0.weight"], accumulate=True)
+        self._bias_grad(dz0, 64, "enhance.in_conv.0.bias")
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, inp, wpH=None, wps=None, keep=True):
+        """inp: [1,3,H,W] in [0,1].  wpH/wps: warped cache (None on a new sequence -> zeros, model.py:155-161).
+        Returns the 23 outputs in the reference order (Appendix B of SURVEY.md)."""
+        o, lib, s = self.ops, self.lib, self._stream()
+        _, _, H, W = inp.shape
+        assert H % 2 == 0 and W % 2 == 0, "H and W must be even (the reference resizes to 1920x1080)"
+        h, w = H // 2, W // 2
+        self.keep = keep
+        self.sv = {}
+        self.repack_weights()
+        x, L11, L12 = self._new(1, 3, H, W), self._new(1, 3, h, w), self._new(1, 3, h, w)
+        Lq11, Lq12 = self._new(1, 3, h, w), self._new(1, 3, h, w)
+        lib.call("zt_prep_input_f32", inp, x, L11, L12, Lq11, Lq12, H, W, s)
+        n11 = self._denoise_fwd(D1, [L11], h, w, 3, 3, "D1a")
+        n12 = self._denoise_fwd(D1, [L12], h, w, 3, 3, "D1b")
+        n = self._denoise_fwd(D1, [x], H, W, 3, 3, "D1c")
+        L2, Lp1, Lp2 = self._new(1, 3, H, W), self._new(1, 3, h, w), self._new(1, 3, h, w)
+        den1, den2 = self._new(1, 3, h, w), self._new(1, 3, h, w)
+        lib.call("zt_d1_tail_f32", x, n, L11, n11, L12, n12, L2, Lp1, Lp2, den1, den2, H, W, s)
+        if wpH is None:
+            wpH, wps = self._zeros(1, 3, H, W), self._zeros(1, 3, H, W)
+            wpH1 = wpH2 = wps1 = wps2 = self._zeros(1, 3, h, w)
+        else:
+            wpH1, wpH2 = o.pair_down(wpH)
+            wps1, wps2 = o.pair_down(wps)
+        s2 = self._enhancer_fwd(wpH, wps, L2, H, W)
+        s21, s22, H2 = self._new(1, 3, h, w), self._new(1, 3, h, w), self._new(1, 3, H, W)
+        H11, H12, H1 = self._new(1, 3, h, w), self._new(1, 3, h, w), self._new(1, 3, H, W)
+        lib.call("zt_post_enh_f32", x, s2, L2, L11, L12, s21, s22, H2, H11, H12, H1, H, W, s)
+        r3 = self._denoise_fwd(D2, [wpH1, wps1, H11, s21], h, w, 12, 6, "D2a")
+        r4 = self._denoise_fwd(D2, [wpH2, wps2, H12, s22], h, w, 12, 6, "D2b")
+        r5 = self._denoise_fwd(D2, [wpH, wps, H2, s2], H, W, 12, 6, "D2c")
+        H3p, H4p, H5p = self._new(1, 6, h, w), self._new(1, 6, h, w), self._new(1, 6, H, W)
+        lib.call("zt_clamp_sub6_f32", H11, s21, r3, H3p, H3p[:, 3:], h * w, s)
+        lib.call("zt_clamp_sub6_f32", H12, s22, r4, H4p, H4p[:, 3:], h * w, s)
+        lib.call("zt_clamp_sub6_f32", H2, s2, r5, H5p, H5p[:, 3:], H * W, s)
+        H3, s3 = H5p[:, :3], H5p[:, 3:]
+        m_l = o.texture_mask(Lp1, Lp2)
+        H3d1, H3d2 = o.pair_down(H3)
+        m_h = o.texture_mask(H3d1, H3d2)
+        tmp = self._new(1, 3, H, W)
+        H2b, H3b = o.blur21(H1, tmp), o.blur21(H3, tmp)
+        if keep:
+            self.sv.update(inp=inp, x=x, n=n, L11=L11, L12=L12, Lq11=Lq11, Lq12=Lq12, L2=L2, Lp1=Lp1, Lp2=Lp2, den1=den1,
+                           den2=den2, s2=s2, s21=s21, s22=s22, H2=H2, H11=H11, H12=H12, r3=r3, r4=r4, r5=r5, H3p=H3p, H4p=H4p,
+                           H3=H3, s3=s3, H3d1=H3d1, H3d2=H3d2, m_h=m_h, H2b=H2b, H3b=H3b, HW=(H, W))
+        return (Lp1, Lp2, L2, s2, s21, s22, H2, H11, H12, H3p[:, :3], H3p[:, 3:], H4p[:, :3], H4p[:, 3:], H3, s3, H3p, H4p,
+                m_l, m_h, H2b, H3b, H3d1, H3d2)
+
+    # ------------------------------------------------------------------------------------------------ loss + backward
+    def loss_grads(self, grads):
+        """Needs a preceding forward(keep=True).  `grads`: {name: zeroed tensor} receiving d loss / d parameter.
+        Returns (loss 0-dim tensor, terms [17])."""
+        o, lib, s, v = self.ops, self.lib, self._stream(), self.sv
+        self.g = grads
+        H, W = v["HW"]
+        h, w = H // 2, W // 2
+        HW, hw = H * W, h * w
+        terms = self._new(17)
+        # ---- scalars (enhancement factor) and the s2 terms
+        nb = max(1, min(256, HW // 4096))
+        part = self._new(nb, 3)
+        lib.call("zt_plane_sums_f32", v["L2"], 3, HW, nb, part, s)
+        scal = self._new(8)
+        lib.call("zt_loss_scalars_f32", part, nb, HW, int(self.is_WB), scal, s)
+        Y = o.ycc_flat(v["L2"])
+        ds2 = self._new(1, 3, H, W)
+        nb1 = ((W + 63) // 64) * ((H + 3) // 4)
+        p1 = self._new(nb1, 4)
+        lib.call("zt_loss_s2_f32", v["L2"], v["s2"], Y, scal, H, W, ds2, p1, s)
+        o.partial_reduce(p1, nb1, 4, 4, out=terms)
+        # ---- half-resolution terms
+        LM1, LM2 = o.box5_reflect(v["H3d1"]), o.box5_reflect(v["H3d2"])
+        dLp1, dLp2, dden1, dden2 = (self._new(1, 3, h, w) for _ in range(4))
+        dH3p, dH4p = self._new(1, 6, h, w), self._new(1, 6, h, w)
+        dH3d1, dH3d2, u1, u2 = (self._new(1, 3, h, w) for _ in range(4))
+        nb2 = (hw + 255) // 256
+        p2 = self._new(nb2, 10)
+        lib.call("zt_loss_half_f32", v["Lq11"], v["Lq12"], v["Lp1"], v["Lp2"], v["den1"], v["den2"], v["H3p"], v["H4p"],
+                 v["H11"], v["s21"], v["H12"], v["s22"], v["H3d1"], v["H3d2"], v["m_h"], LM1, LM2, dLp1, dLp2, dden1, dden2,
+                 dH3p, dH4p, dH3d1, dH3d2, u1, u2, hw, p2, s)
+        lib.call("zt_partial_reduce_f32", p2, nb2, 10, 8, terms.data_ptr() + 16, 0, None, s)
+        lib.call("zt_partial_reduce_f32", p2.data_ptr() + 32, nb2, 10, 2, terms.data_ptr() + 56, 0, None, s)
+        # ---- full-resolution terms
+        DH2, VH2 = o.localvar_fwd(v["H2"])
+        DN, VN = o.localvar_fwd(v["H3"].contiguous() if not v["H3"].is_contiguous() else v["H3"], v["H2"])
+        dH3b, ds3, gV = self._new(1, 3, H, W), self._new(1, 3, H, W), self._new(1, 3, H, W)
+        nb3 = (3 * HW + 255) // 256
+        p3 = self._new(nb3, 3)
+        lib.call("zt_loss_full_f32", v["H2b"], v["H3b"], v["s2"], v["s3"], VH2, VN, dH3b, ds3, gV, 3 * HW, p3, s)
+        lib.call("zt_partial_reduce_f32", p3, nb3, 3, 2, terms.data_ptr() + 48, 0, None, s)
+        lib.call("zt_partial_reduce_f32", p3.data_ptr() + 8, nb3, 3, 1, terms.data_ptr() + 64, 0, None, s)
+        loss = self._new(1)
+        o.partial_reduce(terms, 17, 1, 1, out=loss)
+        # ---- backward: into H3 / H2
+        o.box5_reflect_adj(u1, -1.0, out=dH3d1)
+        o.box5_reflect_adj(u2, -1.0, out=dH3d2)
+        dH3 = o.pair_down_adj(dH3d1, dH3d2, H, W)
+        tmp = self._new(1, 3, H, W)
+        o.blur21_adj(dH3b, out=dH3, tmp=tmp)
+        o.localvar_bwd(DN, gV, -1.0, out=dH3)
+        dH2x = o.localvar_bwd(DH2, gV, 1.0)
+        o.localvar_bwd(DN, gV, 1.0, out=dH2x)
+        # ---- through the three Denoise_2 invocations (model.py:179-192)
+        dr5, dr3, dr4 = self._new(1, H, W, 8), self._new(1, h, w, 8), self._new(1, h, w, 8)
+        lib.call("zt_clamp_sub6_bwd_f32", v["H2"], v["s2"], v["r5"], dH3, ds3, dr5, 8, HW, s)
+        lib.call("zt_clamp_sub6_bwd_f32", v["H11"], v["s21"], v["r3"], dH3p, dH3p[:, 3:], dr3, 8, hw, s)
+        lib.call("zt_clamp_sub6_bwd_f32", v["H12"], v["s22"], v["r4"], dH4p, dH4p[:, 3:], dr4, 8, hw, s)
+        dIn3 = self._denoise_bwd(D2, "D2a", dr3, 6, True)
+        dIn4 = self._denoise_bwd(D2, "D2b", dr4, 6, True)
+        dIn5 = self._denoise_bwd(D2, "D2c", dr5, 6, True)
+        # ---- everything that reaches s2 -> Enhancer
+        dO = self._new(1, H, W, 4)
+        lib.call("zt_post_enh_bwd_f32", v["x"], v["s2"], v["L11"], v["L12"], v["s21"], v["s22"], dIn5, dH2x, dIn3, dIn4, ds2,
+                 dO, 4, None, H, W, s)
+        self._enhancer_bwd(dO)
+        # ---- Denoise_1 x3
+        dn, dn11, dn12 = self._new(1, H, W, 4), self._new(1, h, w, 4), self._new(1, h, w, 4)
+        lib.call("zt_d1_bwd_prep_f32", v["x"], v["n"], dLp1, dLp2, dden1, dden2, dn, dn11, dn12, 4, H, W, s)
+        self._denoise_bwd(D1, "D1a", dn11, 3, False)
+        self._denoise_bwd(D1, "D1b", dn12, 3, False)
+        self._denoise_bwd(D1, "D1c", dn, 3, False)
+        return loss, terms
