@@ -120,6 +120,8 @@ int zt_d1_bwd_prep_f32(const float* x, const float* n, const float* dLp1, const 
                        const float* dden2, float* dn, float* dn11, float* dn12, int ld, int H, int W, zt_stream_t stream);
 /* ReLU backward on nhwc buffers: out = g * [a > 0] */
 int zt_relu_mask_nhwc_f32(const float* g, int ldg, const float* a, int lda, float* out, int ldo, long long npix, int C, zt_stream_t stream);
+/* element-wise helpers of Finetunemodel.forward (model.py:313-316,327-328): mode 0 a+p0; 1 clamp(a-b,p0,p1); 2 clamp(a/b,p0,p1) */
+int zt_ew_f32(const float* a, const float* b, float* out, int mode, float p0, float p1, long long n, zt_stream_t stream);
 int zt_add3_f32(const float* a, const float* b, const float* c, float* out, long long n, zt_stream_t stream);
 
 /* ---- LossFunction.forward (loss.py:12-78) + gradient w.r.t. its inputs (zt_loss.hip) ------------------------------- */
@@ -138,6 +140,28 @@ int zt_loss_half_f32(const float* Lq11, const float* Lq12, const float* Lp1, con
 /* loss.py:64, 66, 75-77: partial[block][3] = color, ill, var; dH3_blur, ds3, gV = d/dV(H2) (= -d/dV(H3-H2)) */
 int zt_loss_full_f32(const float* H2b, const float* H3b, const float* s2, const float* s3, const float* VH2, const float* VN,
                      float* dH3b, float* ds3, float* gV, long long n, float* partial, zt_stream_t stream);
+
+
+/* ---- RAFT / update_cache specific kernels (zt_raft.hip) ------------------------------------------------------------ */
+/* F.interpolate(bilinear, align_corners=False) * mul on planar tensors (model.py:226-227,231), ATen CPU rounding sequence */
+int zt_resize_bilinear_f32(const float* src, float* dst, int C, int H, int W, int h, int w, float mul, zt_stream_t stream);
+/* (x).to(uint8) + per-channel histogram + torchvision==0.18.1 equalize LUT (model.py:234); q: uint8 [C][hw], hist/lut: int32 [C][256] */
+int zt_equalize_prepare_u8(const float* src, unsigned char* q, int* hist, int* lut, int C, int hw, zt_stream_t stream);
+/* raft.py:80-83,132-138: centred replicate pad to multiples of 8, 2*(x/255)-1; frame 1 float, frame 2 = lut[q2]; dst nhwc [2][Hp][Wp][4] */
+int zt_raft_pack_input_f32(const float* img1, const unsigned char* q2, const int* lut, float* dst, int h, int w, int Hp, int Wp, zt_stream_t stream);
+/* corr.py:25-27 one pyramid level: avg_pool2d(2,2) of [npx][hin][win] (row pitch ldin) -> [npx][hin/2][win/2] */
+int zt_corr_pool_f32(const float* src, float* dst, int npx, int hin, int win, int ldin, zt_stream_t stream);
+/* corr.py:29-50 (the seam of alt_cuda_corr.forward, corr.py:86): coords [npx][2] -> out nhwc [npx][ldo>=324], channel = lvl*81 + i*9 + j */
+int zt_corr_lookup_f32(const float* l0, const float* l1, const float* l2, const float* l3, int h, int w, int ld0, const float* coords,
+                       float* out, int ldo, int npx, zt_stream_t stream);
+/* update.py:42-45: rh = r*h with zr = [z|r]; update.py:47: h = (1-z)h + z q */
+int zt_gru_rh_f32(const float* zr, int ldzr, const float* hbuf, int ldh, float* rh, int ldrh, int C, int npx, zt_stream_t stream);
+int zt_gru_update_f32(const float* zr, int ldzr, const float* q, int ldq, float* hbuf, int ldh, int C, int npx, zt_stream_t stream);
+/* raft.py:57-62,112-120: coords grid; coords1 += delta (may be NULL), flow = coords1 - coords0 written to two nhwc destinations */
+int zt_raft_coords_init_f32(float* coords, int h, int w, zt_stream_t stream);
+int zt_raft_flow_step_f32(float* coords1, const float* delta, int ldd, int h, int w, float* f4, int ldf4, float* fhx, int ldfhx, zt_stream_t stream);
+/* raft.py:64-75 upsample_flow: flow nhwc (ldf), mask nhwc [npx][576] -> planar [2][8h][8w]; optional planar flow_low [2][h][w] */
+int zt_convex_upsample_f32(const float* f4, int ldf, const float* mask, int ldm, float* up, float* flow_low, int h, int w, zt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 """End-to-end parity of the hand-written forward / fused loss+gradient / backward plan against the CPU oracle
 and the reference-generated goldens."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -16,6 +17,12 @@ def _engine(ops, dev, synth, seed, is_WB=False):
     params = {n: torch.from_numpy(np.array(st[n])).to(dev) for n in names if n.endswith((".weight", ".bias"))}
     bufs = {n: torch.from_numpy(np.array(st[n])).to(dev) for n in names if "running" in n or "num_batches" in n}
     return eng_mod.Engine(ops, params, bufs, is_WB=is_WB, device=dev), params, bufs
+
+
+def _skip_heavy_emu(bname):
+    """RAFT through the fiber emulator takes minutes; the CPU suite runs it only on request (ZT_EMU_FULL=1)."""
+    if bname == "emu" and not os.environ.get("ZT_EMU_FULL"):
+        pytest.skip("heavy emulator case (set ZT_EMU_FULL=1); covered by -m gpu")
 
 
 def rel_l2(a, b):
@@ -56,3 +63,68 @@ def test_newseq_forward_loss_grads(backend, synth, oracle, name, wb):
             assert float(gr.abs().max()) <= 1e-5 * gn
         else:
             assert rel_l2(gr, ref) < 1e-3, (n, rel_l2(gr, ref))
+
+
+def _network(ops, dev, synth, seed, dataset="RLV", of_scale=1, cls="Network", pretrain=None):
+    import argparse
+    net_mod = importlib.import_module("zero-tig_amd.network")
+    args = argparse.Namespace(dataset=dataset, of_scale=of_scale)
+    if pretrain is not None:
+        args.model_pretrain = pretrain
+    net = getattr(net_mod, cls)(args, ops=ops)
+    if pretrain is None:
+        st = synth.make_state(seed)
+        sd = net.state_dict()
+        assert set(sd.keys()) == set(st.keys())
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()})
+    return net.to(dev)
+
+
+@pytest.mark.parametrize("name", ["g3_seq_128x160", "g4_seq_132x164"])
+def test_sequence_raft_warp_loss_grads(backend, synth, name):
+    """Two-frame sequence through the drop-in Network: frame 1 runs downscale + equalize + RAFT(12) + fused warp."""
+    ops, dev, bname = backend
+    _skip_heavy_emu(bname)
+    g = load_golden(name)
+    H, W, seed, ofs = [int(v) for v in g["meta"]]
+    xs = [f.to(dev) for f in frames(synth, 2, H, W)]
+    net = _network(ops, dev, synth, seed, of_scale=ofs)
+    net.train()
+    net.is_new_seq = True
+    l0 = net._loss(xs[0])
+    assert abs(float(l0) - float(g["loss0"])) <= 1e-4 * abs(float(g["loss0"]))
+    net.zero_grad()
+    net.is_new_seq = False
+    l1 = net._loss(xs[1])
+    l1.backward()
+    wpH, wps = net.last_H3_wp, net.last_s3_wp
+    assert float(np.abs(wpH.cpu().numpy() - g["wpH"]).max()) < 2e-4
+    assert float(np.abs(wps.cpu().numpy() - g["wps"]).max()) < 2e-4
+    assert float(np.abs(net.last_H3.cpu().numpy() - g["last_H3"]).max()) < 2e-4
+    assert abs(float(l1) - float(g["loss1"])) <= 2e-4 * abs(float(g["loss1"]))
+    gn = np.sqrt(sum(float((g[k].astype(np.float64) ** 2).sum()) for k in g.files if k.startswith("grad:")))
+    for n, p in net.named_parameters():
+        if not p.requires_grad or n.startswith("enhance.blocks"):
+            continue
+        ref = g["grad:" + n]
+        if n == "enhance.conv.0.bias":
+            assert float(p.grad.abs().max()) <= 1e-5 * gn
+        else:
+            assert rel_l2(p.grad, ref) < 2e-3, (n, rel_l2(p.grad, ref))
+
+
+def test_raft_flow_golden(backend, synth):
+    """RAFT plan alone on the reference's own RAFT inputs (golden raft_img1/2): flow_low / flow_up parity."""
+    ops, dev, bname = backend
+    _skip_heavy_emu(bname)
+    g = load_golden("g4_seq_132x164")
+    net = _network(ops, dev, synth, int(g["meta"][2]), of_scale=1)
+    _, rp = net._plan()
+    img1, img2 = torch.from_numpy(g["raft_img1"]).to(dev), torch.from_numpy(g["raft_img2"]).to(dev)
+    h, w = img1.shape[-2:]
+    q = img2.to(torch.uint8).view(3, h * w).contiguous()
+    lut = torch.arange(256, dtype=torch.int32, device=dev).repeat(3, 1).contiguous()
+    x2 = ops.raft_pack_input(img1, q, lut, h, w)
+    flow_low, flow_up = rp.run(x2)
+    assert float(np.abs(flow_low.cpu().numpy() - g["flow_low"]).max()) < 5e-4
+    assert float(np.abs(flow_up.cpu().numpy() - g["flow_up"]).max()) < 4e-3

@@ -233,3 +233,69 @@ def test_norms(backend):
     dz = ops.bn_relu_bwd(_nhwc(dy).to(dev), zd, sc, sh, mu, rs, dg, db)
     assert maxerr(dz.cpu().permute(0, 3, 1, 2), z.grad) < 2e-5
     assert maxerr(dg, gam_t.grad) < 2e-4 and maxerr(db, bet_t.grad) < 2e-4
+
+
+def test_raft_ops_golden(backend, oracle, synth):
+    """corr volume (as MFMA 1x1 conv) + pyramid + fused lookup, equalize, one update-block step + convex upsample (G6)."""
+    from importlib import import_module
+    ops, dev, _ = backend
+    CV = import_module("zero-tig_amd.ops").CV
+    g = load_golden("g6_ops")
+    # equalize
+    e_in = torch.from_numpy(g["eq_in"])
+    q, hist, lut = ops.equalize_prepare(e_in.float().to(dev))
+    assert torch.equal(q.cpu().view(3, 30, 44), e_in[0])
+    out = torch.gather(lut.cpu().long(), 1, q.cpu().long()).view(1, 3, 30, 44).to(torch.uint8)
+    assert np.array_equal(out.numpy(), g["eq_out"])
+    const = torch.full((1, 3, 8, 8), 77.0)
+    _, _, lut2 = ops.equalize_prepare(const.to(dev))
+    assert torch.equal(lut2.cpu(), torch.arange(256, dtype=torch.int32).repeat(3, 1))        # step == 0 -> identity
+    # correlation volume / pyramid / lookup
+    h, w = 16, 24
+    f1 = torch.from_numpy(synth.normal("ops.f1", (1, 256, h, w), 0.0, 1.0, 7))
+    f2 = torch.from_numpy(synth.normal("ops.f2", (1, 256, h, w), 0.0, 1.0, 7))
+    corr0 = ops.conv2d(CV(_nhwc(f1).to(dev)), f2.view(1, 256, h * w).to(dev).contiguous(), None, h * w, 1, 1, alpha=1.0 / 16.0)
+    levels = ops.corr_pyramid(corr0, h, w)
+    assert maxerr(corr0.cpu().view(h * w, h, w)[::7], torch.from_numpy(g["corr_pyr0"])[:, 0]) < 2e-5
+    for i, lv in enumerate(levels):
+        assert maxerr(lv, torch.from_numpy(g["corr_pyr%d" % (i + 1)])[:, 0]) < 2e-5
+    coords = torch.from_numpy(g["lookup_coords"])
+    cflat = coords[0].permute(1, 2, 0).reshape(-1, 2).contiguous().to(dev)
+    look = ops.corr_lookup(corr0, levels, h, w, cflat)
+    assert maxerr(look.cpu().permute(0, 3, 1, 2), torch.from_numpy(g["lookup_out"])) < 2e-5
+    # lookup on the ORACLE's pyramid must reproduce ATen's taps/weights bit for bit (integer contract of corr.py:29-50)
+    pyr = oracle.corr_pyramid(f1, f2)
+    c0 = torch.zeros(1, h, w, h * w)
+    c0[0] = pyr[0].view(h, w, h * w)
+    look2 = ops.corr_lookup(c0.to(dev), [p[:, 0].contiguous().to(dev) for p in pyr[1:]], h, w, cflat)
+    assert torch.equal(look2.cpu().permute(0, 3, 1, 2), oracle.corr_lookup(pyr, coords))
+
+
+def test_raft_update_step_golden(backend, oracle, synth):
+    import importlib
+    ops, dev, _ = backend
+    g = load_golden("g6_ops")
+    raft_mod = importlib.import_module("zero-tig_amd.raft")
+    st = synth.make_state(3)
+    W = {k: torch.from_numpy(np.array(v)).to(dev) for k, v in st.items() if k.startswith("raft.")}
+    plan = raft_mod.RaftPlan(ops, W, dev)
+    # drive one refinement step through the plan's building blocks by running `run` internals on prepared state is
+    # covered end-to-end in test_engine (sequence goldens); here: convex upsample against the golden directly.
+    h, w = 16, 24
+    fl = torch.from_numpy(g["lookup_coords"]) - torch.stack(torch.meshgrid(torch.arange(w), torch.arange(h), indexing="xy"), 0).float()[None]
+    dfl = torch.from_numpy(g["ub_dflow"])
+    # recompute the full mask with the oracle (the golden stores every 9th channel) and check it against the golden slice
+    hh = torch.tanh(torch.from_numpy(synth.normal("ops.h", (1, 128, h, w), 0.0, 1.0, 7)))
+    inp = torch.relu(torch.from_numpy(synth.normal("ops.inp", (1, 128, h, w), 0.0, 1.0, 7)))
+    f1 = torch.from_numpy(synth.normal("ops.f1", (1, 256, h, w), 0.0, 1.0, 7))
+    f2 = torch.from_numpy(synth.normal("ops.f2", (1, 256, h, w), 0.0, 1.0, 7))
+    pyr = oracle.corr_pyramid(f1, f2)
+    Wt = oracle.to_torch_state(st)
+    with torch.no_grad():
+        _, mask, dfl_o = oracle.update_block(Wt, "raft.update_block", hh, inp, oracle.corr_lookup(pyr, torch.from_numpy(g["lookup_coords"])), fl)
+    assert maxerr(mask[:, ::9], torch.from_numpy(g["ub_mask"])) < 1e-4
+    f4 = torch.zeros(1, h, w, 4)
+    f4[..., :2] = (fl + dfl_o)[0].permute(1, 2, 0)
+    up = torch.empty(1, 2, 8 * h, 8 * w, device=dev)
+    ops.lib.call("zt_convex_upsample_f32", f4.to(dev), 4, _nhwc(mask).to(dev), 576, up, None, h, w, None if dev.type == "cpu" else torch.cuda.current_stream().cuda_stream)
+    assert maxerr(up, torch.from_numpy(g["ub_up"])) < 1e-4

@@ -228,6 +228,18 @@ __global__ void __launch_bounds__(256) relu_mask_kernel(const float* __restrict_
   *reinterpret_cast<float4*>(out + p * ldo + q * 4) = gv;
 }
 
+// mode 0: a + p0   1: clamp(a - b, p0, p1)   2: clamp(a / b, p0, p1)
+__global__ void __launch_bounds__(256) ew_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                 int mode, float p0, float p1, long long n) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = a[i];
+  if (mode == 0) v = v + p0;
+  else if (mode == 1) v = zt_clampf(v - b[i], p0, p1);
+  else v = zt_clampf(v / b[i], p0, p1);
+  out[i] = v;
+}
+
 inline dim3 grid_half(int H, int W) { return dim3(zt_cdiv(W / 2, 64), zt_cdiv(H / 2, 4)); }
 
 }  // namespace
@@ -322,6 +334,13 @@ extern "C" int zt_relu_mask_nhwc_f32(const float* g, int ldg, const float* a, in
   ZT_REQUIRE(g && a && out && C % 4 == 0 && ldg % 4 == 0 && lda % 4 == 0 && ldo % 4 == 0);
   long long total4 = npix * (C / 4);
   hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, g, ldg, a, lda, out, ldo, C, total4);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_ew_f32(const float* a, const float* b, float* out, int mode, float p0, float p1, long long n, hipStream_t stream) {
+  ZT_REQUIRE(a && out && (mode == 0 || b) && mode >= 0 && mode <= 2);
+  hipLaunchKernelGGL(ew_kernel, dim3((unsigned)zt_cdivl(n, 256)), dim3(256), 0, stream, a, b, out, mode, p0, p1, n);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

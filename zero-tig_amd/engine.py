@@ -147,9 +147,9 @@ class Engine:
         self._bias_grad(dz0, 64, "enhance.in_conv.0.bias")
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, inp, wpH=None, wps=None, keep=True):
-        """inp: [1,3,H,W] in [0,1].  wpH/wps: warped cache (None on a new sequence -> zeros, model.py:155-161).
-        Returns the 23 outputs in the reference order (Appendix B of SURVEY.md)."""
+    def forward(self, inp, cache_fn=None, keep=True):
+        """inp: [1,3,H,W] in [0,1].  cache_fn(L2) -> (warped last_H3, warped last_s3) (model.py:164); None on a new sequence
+        (zeros, model.py:155-161).  Returns the 23 outputs in the reference order (Appendix B of SURVEY.md)."""
         o, lib, s = self.ops, self.lib, self._stream()
         _, _, H, W = inp.shape
         assert H % 2 == 0 and W % 2 == 0, "H and W must be even (the reference resizes to 1920x1080)"
@@ -166,12 +166,14 @@ class Engine:
         L2, Lp1, Lp2 = self._new(1, 3, H, W), self._new(1, 3, h, w), self._new(1, 3, h, w)
         den1, den2 = self._new(1, 3, h, w), self._new(1, 3, h, w)
         lib.call("zt_d1_tail_f32", x, n, L11, n11, L12, n12, L2, Lp1, Lp2, den1, den2, H, W, s)
-        if wpH is None:
+        if cache_fn is None:
             wpH, wps = self._zeros(1, 3, H, W), self._zeros(1, 3, H, W)
             wpH1 = wpH2 = wps1 = wps2 = self._zeros(1, 3, h, w)
         else:
+            wpH, wps = cache_fn(L2)
             wpH1, wpH2 = o.pair_down(wpH)
             wps1, wps2 = o.pair_down(wps)
+        self.last_wp = (wpH, wps)
         s2 = self._enhancer_fwd(wpH, wps, L2, H, W)
         s21, s22, H2 = self._new(1, 3, h, w), self._new(1, 3, h, w), self._new(1, 3, H, W)
         H11, H12, H1 = self._new(1, 3, h, w), self._new(1, 3, h, w), self._new(1, 3, H, W)
@@ -195,6 +197,34 @@ class Engine:
                            H3=H3, s3=s3, H3d1=H3d1, H3d2=H3d2, m_h=m_h, H2b=H2b, H3b=H3b, HW=(H, W))
         return (Lp1, Lp2, L2, s2, s21, s22, H2, H11, H12, H3p[:, :3], H3p[:, 3:], H4p[:, :3], H4p[:, 3:], H3, s3, H3p, H4p,
                 m_l, m_h, H2b, H3b, H3d1, H3d2)
+
+    def forward_infer(self, inp, cache_fn=None):
+        """Finetunemodel.forward (model.py:312-340): full-resolution branch, eval-mode BN; new-sequence Denoise_2 temporal
+        slots are H2 (model.py:330-332).  Returns (H2, H3, s3)."""
+        lib, s = self.lib, self._stream()
+        _, _, H, W = inp.shape
+        self.keep, self.sv, self.training = False, {}, False
+        self.repack_weights()
+        n3 = 3 * H * W
+        x = self._new(1, 3, H, W)
+        lib.call("zt_ew_f32", inp, None, x, 0, 1e-4, 0.0, n3, s)
+        n = self._denoise_fwd(D1, [x], H, W, 3, 3, "D1c")
+        L2 = self._new(1, 3, H, W)
+        lib.call("zt_ew_f32", x, n, L2, 1, 1e-4, 1.0, n3, s)
+        if cache_fn is None:
+            wpH = wps = self._zeros(1, 3, H, W)
+        else:
+            wpH, wps = cache_fn(L2)
+        s2 = self._enhancer_fwd(wpH, wps, L2, H, W)
+        H2 = self._new(1, 3, H, W)
+        lib.call("zt_ew_f32", x, s2, H2, 2, 1e-4, 1.0, n3, s)
+        if cache_fn is None:
+            wpH = wps = H2
+        self.last_wp = (wpH, wps)
+        r5 = self._denoise_fwd(D2, [wpH, wps, H2, s2], H, W, 12, 6, "D2c")
+        H5p = self._new(1, 6, H, W)
+        lib.call("zt_clamp_sub6_f32", H2, s2, r5, H5p, H5p[:, 3:], H * W, s)
+        return H2, H5p[:, :3], H5p[:, 3:]
 
     # ------------------------------------------------------------------------------------------------ loss + backward
     def loss_grads(self, grads):

@@ -152,7 +152,7 @@ class Ops:
         return out
 
     def conv2d(self, x, wdev, bias, Cout, KH, KW, stride=1, pad=(0, 0), act=None, alpha=1.0, x2=None, out=None,
-               out_planar=False, aux=None, epi=0):
+               out_planar=False, aux=None, epi=0, w_coff=0):
         """x: CV/tensor NHWC; optional x2 (CV) supplies channels >= x.C.  out: CV (nhwc) or planar tensor [N,Cout,Ho,Wo]."""
         x = _cv(x)
         Cin, csplit, ldx2, x2p = x.C, 0, 0, None
@@ -180,7 +180,7 @@ class Ops:
         if epi:
             av = _cv(aux)
             auxp, ldaux = av.ptr, av.ld
-        self.lib.call("zt_conv2d_nhwc_f32", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin, wdev, ldw, bias, yptr, ldy,
+        self.lib.call("zt_conv2d_nhwc_f32", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin, wdev.data_ptr() + 4 * w_coff, ldw, bias, yptr, ldy,
                       int(out_planar), Cout, KH, KW, stride, pad[0], pad[1], ACT[act], float(alpha), auxp, ldaux, epi,
                       self._s(x.t))
         return out
@@ -252,4 +252,46 @@ class Ops:
             out = torch.empty((1, z.H, z.W, C), dtype=torch.float32, device=z.t.device)
         o = _cv(out)
         self.lib.call("zt_bn_bwd_apply_f32", dy.ptr, dy.ld, z.ptr, z.ld, scale, shift, mean, rstd, sums, o.ptr, o.ld, HW, C, self._s(z.t))
+        return out
+
+    # ---- RAFT specific (zt_raft.hip) --------------------------------------------------------------------------
+    def resize_bilinear(self, x, h, w, mul=1.0):
+        _, C, H, W = x.shape
+        out = torch.empty((1, C, h, w), dtype=torch.float32, device=x.device)
+        self.lib.call("zt_resize_bilinear_f32", x, out, C, H, W, h, w, float(mul), self._s(x))
+        return out
+
+    def equalize_prepare(self, x255):
+        """x255: [1,C,h,w] float in [0,255] -> (uint8 truncation [C,hw], hist int32 [C,256], lut int32 [C,256])."""
+        _, C, h, w = x255.shape
+        q = torch.empty((C, h * w), dtype=torch.uint8, device=x255.device)
+        hist = torch.empty((C, 256), dtype=torch.int32, device=x255.device)
+        lut = torch.empty((C, 256), dtype=torch.int32, device=x255.device)
+        self.lib.call("zt_equalize_prepare_u8", x255, q, hist, lut, C, h * w, self._s(x255))
+        return q, hist, lut
+
+    def raft_pack_input(self, img1, q2, lut, h, w):
+        Hp, Wp = (h + 7) // 8 * 8, (w + 7) // 8 * 8
+        out = torch.empty((2, Hp, Wp, 4), dtype=torch.float32, device=img1.device)
+        self.lib.call("zt_raft_pack_input_f32", img1, q2, lut, out, h, w, Hp, Wp, self._s(img1))
+        return out
+
+    def corr_pyramid(self, corr0, h, w):
+        """corr0: NHWC [1,h,w,ld>=h*w] level 0 -> [level1, level2, level3] tensors [npx, hl, wl]."""
+        npx, ld = h * w, corr0.shape[-1]
+        levels, src, hin, win, ldin = [], corr0, h, w, ld
+        for _ in range(3):
+            dst = torch.empty((npx, hin // 2, win // 2), dtype=torch.float32, device=corr0.device)
+            self.lib.call("zt_corr_pool_f32", src, dst, npx, hin, win, ldin, self._s(corr0))
+            levels.append(dst)
+            src, hin, win = dst, hin // 2, win // 2
+            ldin = hin * win
+        return levels
+
+    def corr_lookup(self, corr0, levels, h, w, coords, out=None):
+        npx = h * w
+        if out is None:
+            out = torch.empty((1, h, w, 324), dtype=torch.float32, device=corr0.device)
+        self.lib.call("zt_corr_lookup_f32", corr0, levels[0], levels[1], levels[2], h, w, corr0.shape[-1], coords, out,
+                      out.shape[-1], npx, self._s(corr0))
         return out

@@ -1,0 +1,158 @@
+"""Frozen RAFT-basic (reference model/RAFT/{raft,extractor,update,corr}.py) as a static inference plan over the HIP
+kernels: instance-norm feature encoder on both frames, eval-BN context encoder, all-pairs correlation volume as an MFMA
+1x1 convolution, pyramid, 12 refinement iterations (fused 4-level lookup, motion encoder, SepConvGRU, flow head) and
+the convex 8x up-sampling of the last iteration only (the reference computes it 12 times and keeps the last)."""
+import torch
+
+from .lib import current_stream
+from .ops import CV
+
+
+class RaftPlan:
+    def __init__(self, ops, weights, device, prefix="raft"):
+        """weights: {name: tensor on device} with the reference's `raft.*` state-dict names."""
+        self.ops, self.lib, self.dev, self.pre = ops, ops.lib, device, prefix
+        self.W = weights
+        self.wd, self.bn = {}, {}
+        self._prepare()
+
+    def _w(self, name):
+        return self.W[self.pre + "." + name]
+
+    def _prepare(self):
+        o = self.ops
+        for k, v in self.W.items():
+            if not k.startswith(self.pre + ".") or not k.endswith(".weight") or v.dim() != 4:
+                continue
+            name = k[len(self.pre) + 1:-7]
+            if ".gru.conv" in name:
+                continue
+            self.wd[name] = o.repack_weight(v.contiguous())
+        g = "update_block.gru."
+        for sfx in ("1", "2"):
+            wz, wr = self._w(g + "convz" + sfx + ".weight"), self._w(g + "convr" + sfx + ".weight")
+            kh, kw = wz.shape[2], wz.shape[3]
+            buf = torch.zeros((kh * kw, 384, 256), dtype=torch.float32, device=self.dev)
+            o.repack_weight(wz.contiguous(), ldw=256, co_off=0, out=buf)
+            o.repack_weight(wr.contiguous(), ldw=256, co_off=128, out=buf)
+            self.wd[g + "convzr" + sfx] = buf
+            self.W[self.pre + "." + g + "convzr" + sfx + ".bias"] = torch.cat(
+                [self._w(g + "convz" + sfx + ".bias"), self._w(g + "convr" + sfx + ".bias")]).contiguous()
+            self.wd[g + "convq" + sfx] = o.repack_weight(self._w(g + "convq" + sfx + ".weight").contiguous())
+        # eval-mode BatchNorm of the context encoder folded to scale / shift once (running stats are frozen)
+        for k in list(self.W.keys()):
+            if k.startswith(self.pre + ".cnet") and k.endswith(".running_mean") and ".downsample.1." not in k:
+                name = k[len(self.pre) + 1:-13]
+                C = self.W[k].numel()
+                sc, sh, _, _ = o.norm_finalize(None, 1, C, 1, 2, self._w(name + ".weight"), self._w(name + ".bias"),
+                                               self._w(name + ".running_mean"), self._w(name + ".running_var"), dev=self.dev)
+                self.bn[name] = (sc, sh)
+
+    # ------------------------------------------------------------------------------------------------ encoders
+    def _norm(self, y, name, kind, inner_relu, res=None, outer_relu=False):
+        o = self.ops
+        if kind == "instance":
+            yv = CV(y)
+            part = o.chan_stats(y)
+            sc, sh, _, _ = o.norm_finalize(part, yv.N, yv.C, yv.H * yv.W, 0)
+        else:
+            sc, sh = self.bn[name]
+        return o.norm_apply(y, sc, sh, res=res, inner_relu=inner_relu, outer_relu=outer_relu)
+
+    def _conv(self, x, name, cout, k, stride=1, pad=None, act=None, **kw):
+        kh, kw_ = (k, k) if isinstance(k, int) else k
+        pad = (kh // 2, kw_ // 2) if pad is None else pad
+        return self.ops.conv2d(x, self.wd[name], self._w(name + ".bias"), cout, kh, kw_, stride, pad, act, **kw)
+
+    def _res_block(self, p, x, dim, stride, kind):
+        y = self._conv(x, p + ".conv1", dim, 3, stride)
+        y = self._norm(y, p + ".norm1", kind, True)
+        y = self._conv(y, p + ".conv2", dim, 3, 1)
+        if stride != 1:
+            xs = self._conv(x, p + ".downsample.0", dim, 1, stride, pad=(0, 0))
+            xs = self._norm(xs, p + ".norm3", kind, False)
+        else:
+            xs = x
+        return self._norm(y, p + ".norm2", kind, True, res=xs, outer_relu=True)
+
+    def _encoder(self, enc, x, kind):
+        """extractor.py:117-191 up to (not including) the 1x1 output conv."""
+        y = self._conv(CV(x, 0, 3), enc + ".conv1", 64, 7, 2)
+        y = self._norm(y, enc + ".norm1", kind, True)
+        for li, dim, stride in ((1, 64, 1), (2, 96, 2), (3, 128, 2)):
+            y = self._res_block("%s.layer%d.0" % (enc, li), y, dim, stride, kind)
+            y = self._res_block("%s.layer%d.1" % (enc, li), y, dim, 1, kind)
+        return y
+
+    # ------------------------------------------------------------------------------------------------ full inference
+    def run(self, x2, iters=12, want_aux=False):
+        """x2: NHWC [2,Hp,Wp,4] (both padded, normalised frames).  Returns (flow_low [1,2,h8,w8], flow_up [1,2,Hp,Wp])."""
+        o, lib, dev = self.ops, self.lib, self.dev
+        s = current_stream(dev)
+        _, Hp, Wp, _ = x2.shape
+        h, w = Hp // 8, Wp // 8
+        npx = h * w
+        # feature encoder (both frames), correlation volume + pyramid
+        f = self._encoder("fnet", x2, "instance")
+        fmap1 = o.conv2d(CV(f[0:1]), self.wd["fnet.conv2"], self._w("fnet.conv2.bias"), 256, 1, 1)
+        pitch = (npx + 15) // 16 * 16
+        fmap2 = torch.zeros((1, 256, pitch), dtype=torch.float32, device=dev)
+        o.conv2d(CV(f[1:2]), self.wd["fnet.conv2"], self._w("fnet.conv2.bias"), 256, 1, 1, out=fmap2, out_planar=True)
+        corr0 = o.conv2d(CV(fmap1), fmap2, None, npx, 1, 1, alpha=1.0 / 16.0)      # corr.py:52-60: / sqrt(256)
+        levels = o.corr_pyramid(corr0, h, w)
+        # context encoder -> hidden state (tanh) and context (relu) straight into the GRU input buffer
+        c = self._encoder("cnet", x2[0:1], "batch")
+        HX = torch.zeros((1, h, w, 384), dtype=torch.float32, device=dev)     # [net | inp | motion(126) | flow(2)]
+        bias = self._w("cnet.conv2.bias")
+        o.conv2d(CV(c), self.wd["cnet.conv2"], bias, 128, 1, 1, act="tanh", out=CV(HX, 0, 128))
+        o.conv2d(CV(c), self.wd["cnet.conv2"], bias[128:], 128, 1, 1, act="relu", out=CV(HX, 128, 128), w_coff=128)
+        coords1 = torch.empty((npx, 2), dtype=torch.float32, device=dev)
+        lib.call("zt_raft_coords_init_f32", coords1, h, w, s)
+        F4 = torch.zeros((1, h, w, 4), dtype=torch.float32, device=dev)
+        lib.call("zt_raft_flow_step_f32", coords1, None, 0, h, w, F4, 4, HX.data_ptr() + 4 * 382, 384, s)
+        CF = torch.empty((1, h, w, 256), dtype=torch.float32, device=dev)
+        RH = torch.empty((1, h, w, 128), dtype=torch.float32, device=dev)
+        CORR = torch.empty((1, h, w, 324), dtype=torch.float32, device=dev)
+        e, g = "update_block.encoder.", "update_block.gru."
+        aux = {}
+        for it in range(iters):
+            o.corr_lookup(corr0, levels, h, w, coords1, out=CORR)
+            if want_aux and it == 0:
+                aux["corr0"] = CORR.clone()
+            cor1 = self._conv(CORR, e + "convc1", 256, 1, act="relu")
+            self._conv(cor1, e + "convc2", 192, 3, act="relu", out=CV(CF, 0, 192))
+            flo1 = self._conv(CV(F4, 0, 2), e + "convf1", 128, 7, act="relu")
+            self._conv(flo1, e + "convf2", 64, 3, act="relu", out=CV(CF, 192, 64))
+            self._conv(CF, e + "conv", 126, 3, act="relu", out=CV(HX, 256, 126))
+            for sfx, k, pad in (("1", (1, 5), (0, 2)), ("2", (5, 1), (2, 0))):
+                zr = self._conv(HX, g + "convzr" + sfx, 256, k, pad=pad, act="sigmoid")
+                lib.call("zt_gru_rh_f32", zr, 256, HX, 384, RH, 128, 128, npx, s)
+                q = self._conv(CV(RH), g + "convq" + sfx, 128, k, pad=pad, act="tanh", x2=CV(HX, 128, 256))
+                lib.call("zt_gru_update_f32", zr, 256, q, 128, HX, 384, 128, npx, s)
+            fh = self._conv(CV(HX, 0, 128), "update_block.flow_head.conv1", 256, 3, act="relu")
+            delta = self._conv(fh, "update_block.flow_head.conv2", 2, 3)
+            lib.call("zt_raft_flow_step_f32", coords1, delta, delta.shape[-1], h, w, F4, 4, HX.data_ptr() + 4 * 382, 384, s)
+        m1 = self._conv(CV(HX, 0, 128), "update_block.mask.0", 256, 3, act="relu")
+        mask = self._conv(m1, "update_block.mask.2", 576, 1, alpha=0.25)
+        flow_up = torch.empty((1, 2, Hp, Wp), dtype=torch.float32, device=dev)
+        flow_low = torch.empty((1, 2, h, w), dtype=torch.float32, device=dev)
+        lib.call("zt_convex_upsample_f32", F4, 4, mask, 576, flow_up, flow_low, h, w, s)
+        if want_aux:
+            aux.update(fmap1=fmap1, fmap2=fmap2, HX=HX, mask=mask)
+            return flow_low, flow_up, aux
+        return flow_low, flow_up
+
+    def update_cache(self, last_H3, last_s3, L2, of_scale, want_aux=False):
+        """model.py:221-259: down-scale, equalise the current frame, RAFT(12), backward-warp both cached tensors."""
+        o = self.ops
+        _, _, H, W = last_H3.shape
+        ht, wd = H // of_scale, W // of_scale
+        a = o.resize_bilinear(last_H3.contiguous(), ht, wd, 255.0)
+        b = o.resize_bilinear(L2, ht, wd, 255.0)
+        q, _, lut = o.equalize_prepare(b)
+        x2 = o.raft_pack_input(a, q, lut, ht, wd)
+        flow_low, flow_up = self.run(x2)
+        wpH, wps = o.warp2(flow_up, last_H3.contiguous(), last_s3.contiguous())
+        if want_aux:
+            return wpH, wps, flow_low, flow_up
+        return wpH, wps
