@@ -163,6 +163,14 @@ int zt_raft_flow_step_f32(float* coords1, const float* delta, int ldd, int h, in
 /* raft.py:64-75 upsample_flow: flow nhwc (ldf), mask nhwc [npx][576] -> planar [2][8h][8w]; optional planar flow_low [2][h][w] */
 int zt_convex_upsample_f32(const float* f4, int ldf, const float* mask, int ldm, float* up, float* flow_low, int h, int w, zt_stream_t stream);
 
+
+/* ---- optimizer step (zt_optim.hip): nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step (train.py:130-131)
+ * over one flat bucket.  g is multiplied by gscale first (1/world_size after the data-parallel all-reduce).  partial: nblk floats
+ * of workspace.  max_norm <= 0 disables clipping.  gnorm_out (optional): the pre-clip global norm. */
+int zt_clip_adam_f32(float* p, const float* g, float* m, float* v, long long n, float* partial, int nblk, float gscale,
+                     float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,
+                     float* gnorm_out, zt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,3 +128,50 @@ def test_raft_flow_golden(backend, synth):
     flow_low, flow_up = rp.run(x2)
     assert float(np.abs(flow_low.cpu().numpy() - g["flow_low"]).max()) < 5e-4
     assert float(np.abs(flow_up.cpu().numpy() - g["flow_up"]).max()) < 4e-3
+
+
+def test_adam_three_steps(backend, synth):
+    """G7: three iterations of the reference loop (loss.backward, clip_grad_norm_(5), Adam.step) through ClipAdam."""
+    ops, dev, bname = backend
+    _skip_heavy_emu(bname)
+    optim = importlib.import_module("zero-tig_amd.optim")
+    g = load_golden("g7_adam_128x160")
+    H, W, seed, ofs = [int(v) for v in g["meta"]]
+    net = _network(ops, dev, synth, seed, of_scale=ofs)
+    net.train()
+    opt = optim.ClipAdam(net, lr=1e-4, betas=(0.9, 0.999), weight_decay=3e-4, max_norm=5.0)
+    for t, x in enumerate(frames(synth, 3, H, W)):
+        net.is_new_seq = (t == 0)
+        opt.zero_grad()
+        loss = net._loss(x.to(dev))
+        loss.backward()
+        gn = opt.step()
+        assert abs(float(loss) - float(g["loss%d" % t])) <= 3e-4 * abs(float(g["loss%d" % t])), (t, float(loss))
+        assert abs(float(gn) - float(g["gnorm%d" % t])) <= 3e-3 * float(g["gnorm%d" % t]), t
+    for n, p in net.named_parameters():
+        if p.requires_grad and not n.startswith("enhance.blocks"):
+            tol = 6.1e-4 if n == "enhance.conv.0.bias" else 3e-5       # see tests/test_oracle_golden.py
+            assert float((p.detach().cpu() - torch.from_numpy(g["w:" + n])).abs().max()) < tol, n
+    assert int(net.enhance.conv[1].num_batches_tracked) == 9
+
+
+def test_finetune_golden(backend, synth, tmp_path):
+    """G9: Finetunemodel (inference twin) on a new-sequence frame and a RAFT-warped second frame."""
+    ops, dev, bname = backend
+    _skip_heavy_emu(bname)
+    g = load_golden("g9_finetune_128x160")
+    H, W, seed, ofs = [int(v) for v in g["meta"]]
+    st = synth.make_state(seed)
+    ck = str(tmp_path / "ck.pt")
+    torch.save({k: torch.from_numpy(np.array(v)) for k, v in st.items()}, ck)
+    net = _network(ops, dev, synth, seed, of_scale=ofs, cls="Finetunemodel", pretrain=ck)
+    net.raft.load_state_dict({k[5:]: torch.from_numpy(np.array(v)) for k, v in st.items() if k.startswith("raft.")})
+    net = net.to(dev)
+    net.eval()
+    with torch.no_grad():
+        for t, x in enumerate(frames(synth, 2, H, W)):
+            net.is_new_seq = (t == 0)
+            H2, H3, s3 = net(x.to(dev))
+            tol = 2e-5 if t == 0 else 2e-4
+            for nm, o in (("H2", H2), ("H3", H3), ("s3", s3)):
+                assert float(np.abs(o.cpu().numpy() - g["%s_%d" % (nm, t)]).max()) < tol, (nm, t)

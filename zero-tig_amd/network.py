@@ -197,6 +197,15 @@ class _ZeroTIGBase(nn.Module):
             self.__dict__["_sig"] = sig
         return self._eng, self._raftplan
 
+    def flat_params(self):
+        """One contiguous bucket for all trainable tensors (see optim.FlatParams); rebuilt if the storage moved."""
+        from .optim import FlatParams
+        fp = self.__dict__.get("_flat")
+        if fp is None or not fp.intact():
+            fp = FlatParams(self._trainable())
+            self.__dict__["_flat"] = fp
+        return fp
+
     def update_H3(self, H3, s3):                            # model.py:217-219
         self.last_H3 = H3.detach()
         self.last_s3 = s3.detach()
@@ -246,7 +255,16 @@ class Network(_ZeroTIGBase):
     def _loss_and_grads(self, input):
         outs = self._forward_impl(input, keep=True)
         eng = self._eng
-        grads = {n: torch.zeros_like(p) for n, p in self._trainable()}
+        fp = self.__dict__.get("_flat")
+        if fp is not None and fp.intact():
+            scratch = self.__dict__.get("_scratch")
+            if scratch is None or scratch.numel() != fp.n or scratch.device != fp.flat.device:
+                scratch = torch.empty_like(fp.flat)
+                self.__dict__["_scratch"] = scratch
+            scratch.zero_()
+            grads = fp.grad_views(scratch)
+        else:
+            grads = {n: torch.zeros_like(p) for n, p in self._trainable()}
         loss, terms = eng.loss_grads(grads)
         self.__dict__["last_terms"] = terms
         self.update_H3(outs[13], outs[14])                  # model.py:214
