@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 1080p self-supervised Zero-TIG training step (frames/s) on N MI355X of one node.
+
+One "step" = one steady-state frame of the reference loop (train.py:119-131): forward incl. bilinear downscale +
+histogram equalisation + RAFT(12 iterations) + fused backward warp, LossFunction, hand-written backward, one
+flat-bucket gradient all-reduce over RCCL (N > 1), clip_grad_norm_(5) + Adam.  Frames are synthetic
+(zero-tig_amd/synth.py) and already resident in HBM when the timed region starts.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel, measured live with HIP
+events on the launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N == 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--of_scale", type=int, default=3)
+    ap.add_argument("--dataset", type=str, default="RLV")
+    ap.add_argument("--cpu-baseline", type=str, default="540p", choices=["540p", "1080p", "none"])
+    ap.add_argument("--frames", type=int, default=6, help="distinct synthetic frames kept in HBM (cycled)")
+    return ap.parse_args()
+
+
+def cpu_baseline(kind, of_scale, dataset):
+    """The oracle (a torch-CPU restatement of the reference, pinned to reference-generated goldens) timed on the host cores.
+    Sample: one steady-state training step (frame 1 of a clip; frame 0 primes the recurrent cache, untimed)."""
+    from oracle import zt_oracle
+    synth = importlib.import_module("zero-tig_amd.synth")
+    H, W = (540, 960) if kind == "540p" else (1080, 1920)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    tr = zt_oracle.OracleTrainer(zt_oracle.to_torch_state(synth.make_state(1)), is_WB=(dataset == "underwater"), of_scale=of_scale)
+    x0 = torch.from_numpy(synth.lowlight_frame(0, H, W))
+    x1 = torch.from_numpy(synth.lowlight_frame(1, H, W))
+    tr.step(x0, True)
+    t0 = time.perf_counter()
+    tr.step(x1, False)
+    dt = time.perf_counter() - t0
+    scale = (H * W) / (1080.0 * 1920.0)
+    return {"value": (1.0 / dt) * scale, "unit": "frames/s (1080p-equivalent)", "cores": cores, "kind": "port",
+            "sample": "1 steady-state training step (fwd+RAFT+warp+loss+bwd+clip+Adam, fp32) of the CPU oracle at %dx%d in %.2f s, "
+                      "after 1 untimed cache-priming step; scaled by pixel count to 1080p" % (H, W, dt),
+            "seconds_per_step_sample": dt}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    synth = importlib.import_module("zero-tig_amd.synth")
+    net_mod = importlib.import_module("zero-tig_amd.network")
+    optim = importlib.import_module("zero-tig_amd.optim")
+    args = argparse.Namespace(dataset=a.dataset, of_scale=a.of_scale)
+    net = net_mod.Network(args)
+    st = synth.make_state(1)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()})
+    net = net.to(dev)
+    net.train()
+    opt = optim.ClipAdam(net, lr=1e-4, betas=(0.9, 0.999), weight_decay=3e-4, max_norm=5.0)
+
+    H, W = a.height, a.width
+    nfr = max(2, min(a.frames, a.steps + a.warmup + 1))
+    # each rank owns its own clip (seed 2 + 1000*rank): frame-level data parallelism with per-rank recurrent cache
+    frames = [torch.from_numpy(synth.lowlight_frame(t, H, W, seed=2 + 1000 * rank)).to(dev) for t in range(nfr)]
+
+    def step(i):
+        net.is_new_seq = (i == 0)
+        opt.zero_grad()
+        loss = net._loss(frames[i % nfr])
+        loss.backward()
+        opt.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(max(1, a.warmup)):           # at least one step: frame 0 primes the cache (new sequence, no RAFT)
+        step(it)
+        it += 1
+    # live roofline instrumentation of the dominant kernel (Enhancer 64->64 3x3 conv: fwd + dgrad launches)
+    prof = {"match": (3, 3, 1, 64, 64, H, W), "events": []}
+    net._ops.profile = prof
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step(it)
+        it += 1
+    sync()
+    dt = time.perf_counter() - t0
+    net._ops.profile = None
+    last_loss = float(loss)
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    value = world * a.steps / dt
+
+    roof = None
+    if prof["events"]:
+        ms = [s.elapsed_time(e) for s, e in prof["events"]]
+        avg_ms = sum(ms) / len(ms)
+        flops = 2.0 * 9 * 64 * 64 * H * W
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_mfma_f32_kernel<3,3,1,4> (Enhancer 64->64 3x3, fwd+dgrad)", "achieved": ach,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "launches": len(ms), "avg_ms": avg_ms, "algorithmic_flops_per_launch": flops}
+
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_baseline != "none":
+        cpu = cpu_baseline(a.cpu_baseline, a.of_scale, a.dataset)
+
+    if rank == 0:
+        out = {"metric": "1080p self-supervised training frames/sec", "value": value, "unit": "frames/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%dx%d BVI-RLV-style self-supervised training step (enhance+RAFT flow+warp+loss+backward+clip+Adam), "
+                                      "batch 1 frame per GPU, of_scale=%d, dataset=%s" % (H, W, a.of_scale, a.dataset),
+                          "parallelism": "dp%d (one contiguous clip per rank, one 370 KB flat-bucket all-reduce per step)" % world,
+                          "global_batch": world},
+               "roofline": roof, "cpu_baseline": cpu, "final_loss": last_loss}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

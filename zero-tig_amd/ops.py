@@ -180,9 +180,17 @@ class Ops:
         if epi:
             av = _cv(aux)
             auxp, ldaux = av.ptr, av.ld
+        prof = getattr(self, "profile", None)
+        timed = prof is not None and prof["match"] == (KH, KW, stride, Cin, Cout, x.H, x.W)
+        if timed:       # live roofline measurement (bench.py): HIP events on the launch stream around this kernel
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         self.lib.call("zt_conv2d_nhwc_f32", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin, wdev.data_ptr() + 4 * w_coff, ldw, bias, yptr, ldy,
                       int(out_planar), Cout, KH, KW, stride, pad[0], pad[1], ACT[act], float(alpha), auxp, ldaux, epi,
                       self._s(x.t))
+        if timed:
+            e1.record()
+            prof["events"].append((e0, e1))
         return out
 
     def slab(self, dev, nbytes=96 << 20):
