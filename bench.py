@@ -40,22 +40,40 @@ def parse():
     return ap.parse_args()
 
 
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Usable host cores: affinity mask capped by the cgroup CPU quota (the GPU box grants a share of a big host)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(kind, of_scale, dataset):
     """The oracle (a torch-CPU restatement of the reference, pinned to reference-generated goldens) timed on the host cores.
     Sample: one steady-state training step (frame 1 of a clip; frame 0 primes the recurrent cache, untimed)."""
     from oracle import zt_oracle
     synth = importlib.import_module("zero-tig_amd.synth")
     H, W = (540, 960) if kind == "540p" else (1080, 1920)
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log("cpu_baseline: oracle on %d host threads at %dx%d (cache-priming step)" % (cores, H, W))
     tr = zt_oracle.OracleTrainer(zt_oracle.to_torch_state(synth.make_state(1)), is_WB=(dataset == "underwater"), of_scale=of_scale)
     x0 = torch.from_numpy(synth.lowlight_frame(0, H, W))
     x1 = torch.from_numpy(synth.lowlight_frame(1, H, W))
     tr.step(x0, True)
+    log("cpu_baseline: timed steady-state step")
     t0 = time.perf_counter()
     tr.step(x1, False)
     dt = time.perf_counter() - t0
@@ -95,7 +113,11 @@ def main():
     H, W = a.height, a.width
     nfr = max(2, min(a.frames, a.steps + a.warmup + 1))
     # each rank owns its own clip (seed 2 + 1000*rank): frame-level data parallelism with per-rank recurrent cache
-    frames = [torch.from_numpy(synth.lowlight_frame(t, H, W, seed=2 + 1000 * rank)).to(dev) for t in range(nfr)]
+    frames = []
+    for t in range(nfr):
+        frames.append(torch.from_numpy(synth.lowlight_frame(t, H, W, seed=2 + 1000 * rank)).to(dev))
+        if rank == 0:
+            log("synthetic frame %d/%d resident in HBM" % (t + 1, nfr))
 
     def step(i):
         net.is_new_seq = (i == 0)
@@ -111,6 +133,8 @@ def main():
         torch.cuda.synchronize()
 
     it = 0
+    if rank == 0:
+        log("warm-up")
     for _ in range(max(1, a.warmup)):           # at least one step: frame 0 primes the cache (new sequence, no RAFT)
         step(it)
         it += 1
@@ -125,7 +149,9 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     net._ops.profile = None
-    last_loss = float(loss)
+    last_loss = float(loss.detach())
+    if rank == 0:
+        log("timed region done: %.2f ms/step" % (1e3 * dt / a.steps))
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -31,8 +31,8 @@ def run(H=128, W=160, seed=1):
         loss.backward()
         opt.step()
         ref, _, outs, _, _, _ = tr.step(x, t == 0)
-        rel = abs(float(loss) - float(ref)) / abs(float(ref))
+        rel = abs(float(loss.detach()) - float(ref)) / abs(float(ref))
         err = float((net.last_H3.cpu() - outs[13].detach()).abs().max())
         print("smoke frame %d: loss %.5f (oracle %.5f, rel %.2e), max|H3 - oracle| %.2e" % (t, float(loss), float(ref), rel, err))
-        assert rel < 1e-3 and err < 1e-3, (rel, err)
+        assert rel < 1e-3 and err < 5e-3, (rel, err)      # frame 1 follows an Adam step (+-lr sign flips, see tests)
     print("smoke ok; native library:", net._ops.lib.path)
