@@ -1,0 +1,70 @@
+"""Minimal, API-compatible frame loaders (reference dataloader/multi_read_data.py): items are
+(tensor[3,1080,1920] in [0,1], img_name, img_path, last_img_path), frames in temporal order.  PIL only (no torchvision)."""
+import glob
+import os
+
+import numpy as np
+import torch
+import torch.utils.data
+from PIL import Image
+
+
+def _natural(files):
+    def key(f):
+        stem = os.path.splitext(os.path.basename(f))[0]
+        return (0, int(stem)) if stem.isdigit() else (1, stem)
+    return sorted(files, key=key)
+
+
+class _Base(torch.utils.data.Dataset):
+    size = (1920, 1080)
+
+    def initialize(self, args, task):
+        self.args, self.task = args, task
+        self.low_img_dir = args.lowlight_images_path
+        assert os.path.exists(self.low_img_dir), "Input directory does not exist!"
+        self.files = self.list_files(self.low_img_dir, task)
+        assert self.files, "No input data."
+        self.last_path = self.files[0]
+
+    def load(self, f):
+        im = Image.open(f).convert("RGB").resize(self.size)          # multi_read_data.py:127-132 (PIL default filter)
+        return torch.from_numpy(np.asarray(im, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+
+    def __getitem__(self, i):
+        path = self.files[i]
+        last, self.last_path = self.last_path, path
+        return self.load(path), os.path.splitext(os.path.basename(path))[0], path, last
+
+    def __len__(self):
+        return len(self.files)
+
+
+class RLVDataLoader(_Base):
+    """BVI-RLV layout: <root>/<task>_list.txt names scene folders; frames under input/<scene>/low_light_{10,20}/*.png."""
+
+    def name(self):
+        return "BVI-RLV"
+
+    def list_files(self, root, task):
+        assert task in ("train", "test"), "Invalid phase: " + str(task)
+        out = []
+        with open(os.path.join(root, task + "_list.txt")) as fh:
+            for scene in [l.strip() for l in fh if l.strip()]:
+                for sub in ("low_light_10", "low_light_20"):
+                    out += _natural(glob.glob(os.path.join(root, "input", scene, sub, "*.png")))
+        return out
+
+
+class FolderSequenceDataset(_Base):
+    """Generic layout: <root>/<sequence>/*.png (every sub-folder is one sequence)."""
+
+    def name(self):
+        return "FolderSequence"
+
+    def list_files(self, root, task):
+        out = []
+        for d in sorted(glob.glob(os.path.join(root, "*"))):
+            if os.path.isdir(d):
+                out += _natural(glob.glob(os.path.join(d, "*.png")))
+        return out or _natural(glob.glob(os.path.join(root, "*.png")))

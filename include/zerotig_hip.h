@@ -122,6 +122,8 @@ int zt_d1_bwd_prep_f32(const float* x, const float* n, const float* dLp1, const 
 int zt_relu_mask_nhwc_f32(const float* g, int ldg, const float* a, int lda, float* out, int ldo, long long npix, int C, zt_stream_t stream);
 /* element-wise helpers of Finetunemodel.forward (model.py:313-316,327-328): mode 0 a+p0; 1 clamp(a-b,p0,p1); 2 clamp(a/b,p0,p1) */
 int zt_ew_f32(const float* a, const float* b, float* out, int mode, float p0, float p1, long long n, zt_stream_t stream);
+/* utils.py:228 overlap_tensor = 0.5*warped + 0.5*img2: out = alpha*a + beta*b */
+int zt_axpby_f32(const float* a, const float* b, float* out, float alpha, float beta, long long n, zt_stream_t stream);
 int zt_add3_f32(const float* a, const float* b, const float* c, float* out, long long n, zt_stream_t stream);
 
 /* ---- LossFunction.forward (loss.py:12-78) + gradient w.r.t. its inputs (zt_loss.hip) ------------------------------- */
@@ -149,6 +151,8 @@ int zt_resize_bilinear_f32(const float* src, float* dst, int C, int H, int W, in
 int zt_equalize_prepare_u8(const float* src, unsigned char* q, int* hist, int* lut, int C, int hw, zt_stream_t stream);
 /* raft.py:80-83,132-138: centred replicate pad to multiples of 8, 2*(x/255)-1; frame 1 float, frame 2 = lut[q2]; dst nhwc [2][Hp][Wp][4] */
 int zt_raft_pack_input_f32(const float* img1, const unsigned char* q2, const int* lut, float* dst, int h, int w, int Hp, int Wp, zt_stream_t stream);
+/* the same head for two float frames in [0,255] (RAFT.forward called directly, raft.py:77-83) */
+int zt_raft_pack_pair_f32(const float* img1, const float* img2, float* dst, int h, int w, int Hp, int Wp, zt_stream_t stream);
 /* corr.py:25-27 one pyramid level: avg_pool2d(2,2) of [npx][hin][win] (row pitch ldin) -> [npx][hin/2][win/2] */
 int zt_corr_pool_f32(const float* src, float* dst, int npx, int hin, int win, int ldin, zt_stream_t stream);
 /* corr.py:29-50 (the seam of alt_cuda_corr.forward, corr.py:86): coords [npx][2] -> out nhwc [npx][ldo>=324], channel = lvl*81 + i*9 + j */

@@ -1,0 +1,130 @@
+"""The drop-in boundary: ABI symbols, header/ctypes agreement, reference module paths and class surface (CPU),
+and the drop-in functions against the oracle (emulated backend on CPU, real library with -m gpu)."""
+import argparse
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, frames, load_golden
+
+
+def test_header_symbols_exported_by_hip_library():
+    """libzerotig_hip.so loads here (no GPU needed to dlopen) and exports every function include/zerotig_hip.h declares."""
+    lib_mod = importlib.import_module("zero-tig_amd.lib")
+    so = os.path.join(ROOT, "zero-tig_amd", "libzerotig_hip.so")
+    if not os.path.exists(so):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = lib_mod.Lib(so)
+    assert len(lib.protos) >= 45 and set(lib.fns) == set(lib.protos)
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(lib.protos) <= exported
+    assert {s for s in exported if s.startswith("zt_")} == set(lib.protos), "exported zt_* symbols must all be declared in the header"
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib_mod = importlib.import_module("zero-tig_amd.lib")
+    with pytest.raises(RuntimeError):
+        lib_mod.get_lib()
+    net_mod = importlib.import_module("zero-tig_amd.network")
+    net = net_mod.Network(argparse.Namespace(dataset="RLV", of_scale=3))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 16, 16))
+    # and the product never imports the oracle
+    src = ""
+    for f in os.listdir(os.path.join(ROOT, "zero-tig_amd")):
+        if f.endswith(".py") and f != "smoke.py":
+            src += open(os.path.join(ROOT, "zero-tig_amd", f)).read()
+    assert "zt_oracle" not in src and "from oracle" not in src
+
+
+def test_state_dict_surface(synth):
+    """Same 223 keys / shapes / aliases / trainable set as the reference Network."""
+    sys.path.insert(0, ROOT)
+    model_mod = importlib.import_module("model.model")
+    net = model_mod.Network(argparse.Namespace(dataset="RLV", of_scale=3))
+    sd = net.state_dict()
+    inv = dict(synth.inventory())
+    assert len(sd) == 223 and set(sd) == set(inv)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(inv[k]), k
+    trainable = [n for n, p in net.named_parameters() if p.requires_grad]
+    assert len(trainable) == 20 and sum(p.numel() for p in net.parameters() if p.requires_grad) == 92620
+    assert sd["enhance.blocks.1.0.weight"].data_ptr() == sd["enhance.conv.0.weight"].data_ptr()
+    net.enhance.in_conv.apply(net.enhance_weights_init)          # train.py:82-84
+    assert float(net.enhance.in_conv[0].bias.abs().max()) == 0.0
+    assert hasattr(net, "is_new_seq") and hasattr(net, "update_H3") and hasattr(net, "update_cache") and net.of_scale == 3
+    wb = model_mod.Network(argparse.Namespace(dataset="underwater", of_scale=3))
+    assert wb.is_WB and not net.is_WB
+    for name in ("LossFunction", "TextureDifference", "blur", "pair_downsampler", "warp_tensor", "InputPadder", "RAFT", "Finetunemodel"):
+        assert hasattr(model_mod, name), name
+
+
+def test_sequential_judgment(tmp_path):
+    utils = importlib.import_module("utils.utils")
+    a = tmp_path / "s1"
+    b = tmp_path / "s2"
+    a.mkdir(), b.mkdir()
+    for d, n in ((a, "0001"), (a, "0002"), (a, "0004"), (b, "0005")):
+        (d / (n + ".png")).write_bytes(b"x")
+    assert not utils.sequential_judgment(str(a / "0002.png"), str(a / "0001.png"))
+    assert utils.sequential_judgment(str(a / "0004.png"), str(a / "0002.png"))        # gap
+    assert utils.sequential_judgment(str(b / "0005.png"), str(a / "0004.png"))        # directory change
+    assert utils.sequential_judgment(str(a / "0001.png"), str(a / "0001.png"))        # first frame (loader hands itself)
+    with pytest.raises(AssertionError):
+        utils.sequential_judgment(str(a / "0009.png"), str(a / "0001.png"))
+
+
+def test_dataloader_api(tmp_path):
+    from PIL import Image
+    root = tmp_path / "data"
+    for sub in ("low_light_10", "low_light_20"):
+        d = root / "input" / "S01" / sub
+        d.mkdir(parents=True)
+        for i in (2, 1, 10):
+            Image.fromarray(np.full((8, 12, 3), i, np.uint8)).save(str(d / ("%05d.png" % i)))
+    (root / "train_list.txt").write_text("S01\n")
+    cd = importlib.import_module("dataloader.create_data")
+    ds = cd.CreateDataset(argparse.Namespace(dataset="RLV", lowlight_images_path=str(root)), "train")
+    assert len(ds) == 6 and ds.name() == "BVI-RLV"
+    x, name, path, last = ds[0]
+    assert tuple(x.shape) == (3, 1080, 1920) and name == "00001" and last == path and abs(float(x.max()) - 1 / 255) < 1e-6
+    x, name, path, last = ds[1]
+    assert name == "00002" and last.endswith("00001.png")
+
+
+def test_dropin_loss_and_utils(backend, oracle, synth):
+    """loss.LossFunction / TextureDifference / SmoothLoss / L_TV and the CorrBlock seam through the C ABI vs the oracle."""
+    ops, dev, _ = backend
+    sys.path.insert(0, ROOT)
+    loss_mod = importlib.import_module("loss")
+    g = load_golden("g12_newseq_rlv_48x64")
+    H, W, seed, _ = [int(v) for v in g["meta"]]
+    x = frames(synth, 1, H, W)[0]
+    outs = [torch.from_numpy(g["out%02d" % i]).to(dev) for i in range(23)]
+    lf = loss_mod.LossFunction(False, ops=ops)
+    val = lf(x.to(dev), *outs[:21])
+    ref, _ = oracle.loss_terms(x, [o.cpu() for o in outs], False)
+    assert abs(float(val) - float(ref)) <= 1e-4 * abs(float(ref))
+    assert abs(float(val) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    s = loss_mod.SmoothLoss(ops=ops)(outs[2], outs[3])
+    assert abs(float(s) - float(oracle.smooth_loss(outs[2].cpu(), outs[3].cpu()))) <= 1e-4 * float(s)
+    tv = loss_mod.L_TV(ops=ops)(outs[3])
+    assert abs(float(tv) - float(oracle.tv_loss(outs[3].cpu()))) <= 1e-4 * float(tv)
+    m = loss_mod.TextureDifference(ops=ops)(outs[21], outs[22])
+    assert (m.cpu().numpy() != g["out18"]).mean() <= 1e-3
+    corr_mod = importlib.import_module("model.RAFT.corr")
+    f1 = torch.from_numpy(synth.normal("ops.f1", (1, 256, 16, 24), 0.0, 1.0, 7))
+    f2 = torch.from_numpy(synth.normal("ops.f2", (1, 256, 16, 24), 0.0, 1.0, 7))
+    cb = corr_mod.CorrBlock(f1.to(dev), f2.to(dev), radius=4, ops=ops)
+    g6 = load_golden("g6_ops")
+    look = cb(torch.from_numpy(g6["lookup_coords"]).to(dev))
+    assert float((look.cpu() - torch.from_numpy(g6["lookup_out"])).abs().max()) < 2e-5

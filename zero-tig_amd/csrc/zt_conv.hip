@@ -299,21 +299,32 @@ __global__ void __launch_bounds__(256) wgrad_mfma_f32_kernel(WgradArgs a) {
   }
 }
 
-// grad[co][ci][ky][kx] (+)= sum_slabs slab[s][tap][ci][co]
+// grad[co][ci][ky][kx] (+)= sum_slabs slab[s][tap][ci][co].  64 slab elements (co fastest -> coalesced) x 4 slab groups
+// per workgroup; fixed summation order (deterministic).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int ntap, int CT16,
                                                            int NT16, float* __restrict__ grad, int Cout, int Cin,
                                                            int accumulate) {
-  int idx = blockIdx.x * 256 + threadIdx.x;
-  int total = Cout * Cin * ntap;
-  if (idx >= total) return;
-  int tap = idx % ntap;
-  int ci = (idx / ntap) % Cin;
-  int co = idx / (ntap * Cin);
-  size_t stride = (size_t)ntap * CT16 * NT16;
-  const float* p = slab + ((size_t)tap * CT16 + ci) * NT16 + co;
+  __shared__ float sh[256];
+  const int ex = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + ex;
+  const int total = ntap * CT16 * NT16;
   float s = 0.f;
-  for (int k = 0; k < nslab; ++k) s += p[(size_t)k * stride];
-  grad[idx] = accumulate ? grad[idx] + s : s;
+  if (e < total) {
+    const size_t stride = (size_t)total;
+    for (int k = sg; k < nslab; k += 4) s += slab[(size_t)k * stride + e];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (sg == 0 && e < total) {
+    s = ((sh[ex] + sh[64 + ex]) + sh[128 + ex]) + sh[192 + ex];
+    int co = e % NT16;
+    int ci = (e / NT16) % CT16;
+    int tap = e / (NT16 * CT16);
+    if (co < Cout && ci < Cin) {
+      size_t o = ((size_t)co * Cin + ci) * ntap + tap;
+      grad[o] = accumulate ? grad[o] + s : s;
+    }
+  }
 }
 
 template <int KH, int KW>
@@ -394,15 +405,15 @@ extern "C" int zt_conv2d_wgrad_nhwc_f32(const float* x, int ldx, const float* dz
   a.tilesX = zt_cdiv(W, WTW);
   a.ntiles = a.tilesX * zt_cdiv(H, WTH);
   size_t per = (size_t)KH * KW * CT * 16 * NT * 16 * sizeof(float);
-  int nblk = a.ntiles < 512 ? a.ntiles : 512;
+  int nblk = a.ntiles < 256 ? a.ntiles : 256;     // one resident workgroup per CU walks the pixel tiles
   if ((size_t)nblk * per > slab_bytes) nblk = (int)(slab_bytes / per);
   ZT_REQUIRE(nblk >= 1);
   int rc = ZT_EINVAL;
   if (KH == 3 && KW == 3) rc = launch_wgrad<3, 3>(a, CT, NT, nblk, stream);
   else if (KH == 1 && KW == 1) rc = launch_wgrad<1, 1>(a, CT, NT, nblk, stream);
   if (rc) return rc;
-  int total = Cout * Cin * KH * KW;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(zt_cdiv(total, 256)), dim3(256), 0, stream, (const float*)slab, nblk,
+  int total = KH * KW * CT * 16 * NT * 16;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(zt_cdiv(total, 64)), dim3(256), 0, stream, (const float*)slab, nblk,
                      KH * KW, CT * 16, NT * 16, grad_w, Cout, Cin, accumulate);
   ZT_LAUNCH_CHECK();
   return ZT_OK;

@@ -240,6 +240,13 @@ __global__ void __launch_bounds__(256) ew_kernel(const float* __restrict__ a, co
   out[i] = v;
 }
 
+// out = alpha * a + beta * b
+__global__ void __launch_bounds__(256) axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                    float alpha, float beta, long long n) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = alpha * a[i] + beta * b[i];
+}
+
 inline dim3 grid_half(int H, int W) { return dim3(zt_cdiv(W / 2, 64), zt_cdiv(H / 2, 4)); }
 
 }  // namespace
@@ -341,6 +348,13 @@ extern "C" int zt_relu_mask_nhwc_f32(const float* g, int ldg, const float* a, in
 extern "C" int zt_ew_f32(const float* a, const float* b, float* out, int mode, float p0, float p1, long long n, hipStream_t stream) {
   ZT_REQUIRE(a && out && (mode == 0 || b) && mode >= 0 && mode <= 2);
   hipLaunchKernelGGL(ew_kernel, dim3((unsigned)zt_cdivl(n, 256)), dim3(256), 0, stream, a, b, out, mode, p0, p1, n);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_axpby_f32(const float* a, const float* b, float* out, float alpha, float beta, long long n, hipStream_t stream) {
+  ZT_REQUIRE(a && b && out);
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)zt_cdivl(n, 256)), dim3(256), 0, stream, a, b, out, alpha, beta, n);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(256) chan_stats_kernel(const float* __restrict
 }
 
 // mode 0: instance norm (per n,c; no affine)   mode 1: train BN (N must be 1; updates running stats)   mode 2: eval BN
+// 256 threads = G groups x C channels (G = 256 / C): each group sums a strided share of the partials, fp64 combine in LDS.
 __global__ void __launch_bounds__(256) norm_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                             double count, float eps, int mode,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -50,37 +51,55 @@ __global__ void __launch_bounds__(256) norm_finalize_kernel(const float* __restr
                                                             long long* __restrict__ nbt, float momentum,
                                                             float* __restrict__ scale, float* __restrict__ shift,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  __shared__ double sh_s[256];
+  __shared__ double sh_q[256];
   const int n = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float mean, rstd;
-    if (mode == 2) {
-      mean = running_mean[c];
-      rstd = 1.f / sqrtf(running_var[c] + eps);
-    } else {
-      double s = 0.0, q = 0.0;
-      for (int b = 0; b < nblk; ++b) {
+  const int Cb = C < 256 ? C : 256;                 // channels handled per pass
+  const int G = 256 / Cb;
+  for (int cbase = 0; cbase < C; cbase += Cb) {
+    const int cl = threadIdx.x % Cb, grp = threadIdx.x / Cb;
+    const int c = cbase + cl;
+    double s = 0.0, q = 0.0;
+    if (mode != 2 && grp < G && c < C) {
+      for (int b = grp; b < nblk; b += G) {
         const float* p = partial + ((size_t)(n * nblk + b) * 2) * C;
         s += (double)p[c];
         q += (double)p[C + c];
       }
-      double m = s / count;
-      double var = q / count - m * m;
-      if (var < 0.0) var = 0.0;
-      mean = (float)m;
-      rstd = (float)(1.0 / sqrt(var + (double)eps));
-      if (mode == 1) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        float unbiased = (float)(var * count / (count - 1.0));
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-      }
     }
-    float g = (mode == 0) ? 1.f : gamma[c];
-    float b = (mode == 0) ? 0.f : beta[c];
-    float sc = g * rstd;
-    scale[n * C + c] = sc;
-    shift[n * C + c] = b - mean * sc;
-    if (mean_out) mean_out[n * C + c] = mean;
-    if (rstd_out) rstd_out[n * C + c] = rstd;
+    sh_s[threadIdx.x] = s;
+    sh_q[threadIdx.x] = q;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+      float mean, rstd;
+      if (mode == 2) {
+        mean = running_mean[c];
+        rstd = 1.f / sqrtf(running_var[c] + eps);
+      } else {
+        for (int k = 1; k < G; ++k) {
+          s += sh_s[k * Cb + cl];
+          q += sh_q[k * Cb + cl];
+        }
+        double m = s / count;
+        double var = q / count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (mode == 1) {
+          running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+          float unbiased = (float)(var * count / (count - 1.0));
+          running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+      }
+      float g = (mode == 0) ? 1.f : gamma[c];
+      float b = (mode == 0) ? 0.f : beta[c];
+      float sc = g * rstd;
+      scale[n * C + c] = sc;
+      shift[n * C + c] = b - mean * sc;
+      if (mean_out) mean_out[n * C + c] = mean;
+      if (rstd_out) rstd_out[n * C + c] = rstd;
+    }
+    __syncthreads();
   }
   if (mode == 1 && nbt && threadIdx.x == 0 && blockIdx.x == 0) *nbt += 1;
 }
@@ -153,17 +172,26 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// out[j] (+)= sum_b partial[b*stride + j]   (fp64 combine); optional second destination without accumulation
+// out[j] (+)= sum_b partial[b*stride + j]   (fp64 combine); optional second destination without accumulation.
+// One workgroup per output element: 256 threads stride over the partials, fixed-order LDS tree (deterministic).
 __global__ void __launch_bounds__(256) partial_reduce_kernel(const float* __restrict__ partial, int nblk, int stride, int n,
                                                              float* __restrict__ out, int accumulate,
                                                              float* __restrict__ out2) {
-  int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  __shared__ double sh[256];
+  const int j = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * stride + j];
-  float v = (float)s;
-  if (out) out[j] = accumulate ? out[j] + v : v;
-  if (out2) out2[j] = v;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += (double)partial[(size_t)b * stride + j];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float v = (float)sh[0];
+    if (out) out[j] = accumulate ? out[j] + v : v;
+    if (out2) out2[j] = v;
+  }
 }
 
 // dz = gamma*rstd * (dyh - sum_dyh/n - zhat * sum_dyh_zhat/n)
@@ -242,8 +270,7 @@ extern "C" int zt_bn_bwd_reduce_f32(const float* dy, int lddy, const float* z, i
 extern "C" int zt_partial_reduce_f32(const float* partial, int nblk, int stride, int n, float* out, int accumulate,
                                      float* out2, hipStream_t stream) {
   ZT_REQUIRE(partial && n > 0 && (out || out2));
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3(zt_cdiv(n, 256)), dim3(256), 0, stream, partial, nblk, stride, n, out,
-                     accumulate, out2);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(n), dim3(256), 0, stream, partial, nblk, stride, n, out, accumulate, out2);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

@@ -120,6 +120,21 @@ __global__ void __launch_bounds__(256) raft_pack_kernel(const float* __restrict_
   *reinterpret_cast<float4*>(dst + (size_t)Hp * Wp * 4 + o) = b;
 }
 
+// same head for two float frames (RAFT.forward called directly, raft.py:77-83)
+__global__ void __launch_bounds__(256) raft_pack_pair_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
+                                                             float* __restrict__ dst, int h, int w, int Hp, int Wp, int top,
+                                                             int left) {
+  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= Wp || y >= Hp) return;
+  int sy = min(max(y - top, 0), h - 1), sx = min(max(x - left, 0), w - 1);
+  size_t so = (size_t)sy * w + sx, hw = (size_t)h * w;
+  float4 a = make_float4(2.f * (img1[so] / 255.f) - 1.f, 2.f * (img1[hw + so] / 255.f) - 1.f, 2.f * (img1[2 * hw + so] / 255.f) - 1.f, 0.f);
+  float4 b = make_float4(2.f * (img2[so] / 255.f) - 1.f, 2.f * (img2[hw + so] / 255.f) - 1.f, 2.f * (img2[2 * hw + so] / 255.f) - 1.f, 0.f);
+  size_t o = ((size_t)y * Wp + x) * 4;
+  *reinterpret_cast<float4*>(dst + o) = a;
+  *reinterpret_cast<float4*>(dst + (size_t)Hp * Wp * 4 + o) = b;
+}
+
 // corr.py:25-27: avg_pool2d(2, stride 2) over the (h2, w2) axes of [npx][hin][win] -> [npx][hin/2][win/2]
 __global__ void __launch_bounds__(256) corr_pool_kernel(const float* __restrict__ src, float* __restrict__ dst, int npx,
                                                         int hin, int win, int ldin, int hout, int wout) {
@@ -298,6 +313,15 @@ extern "C" int zt_raft_pack_input_f32(const float* img1, const unsigned char* q2
   int top = (Hp - h) / 2, left = (Wp - w) / 2;
   hipLaunchKernelGGL(raft_pack_kernel, dim3(zt_cdiv(Wp, 64), zt_cdiv(Hp, 4)), dim3(64, 4), 0, stream, img1, q2, lut, dst, h, w,
                      Hp, Wp, top, left);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_raft_pack_pair_f32(const float* img1, const float* img2, float* dst, int h, int w, int Hp, int Wp,
+                                     hipStream_t stream) {
+  ZT_REQUIRE(img1 && img2 && dst && Hp >= h && Wp >= w && Hp % 8 == 0 && Wp % 8 == 0 && Hp - h < 8 && Wp - w < 8);
+  hipLaunchKernelGGL(raft_pack_pair_kernel, dim3(zt_cdiv(Wp, 64), zt_cdiv(Hp, 4)), dim3(64, 4), 0, stream, img1, img2, dst, h, w,
+                     Hp, Wp, (Hp - h) / 2, (Wp - w) / 2);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

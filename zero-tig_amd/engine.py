@@ -227,12 +227,9 @@ class Engine:
         return H2, H5p[:, :3], H5p[:, 3:]
 
     # ------------------------------------------------------------------------------------------------ loss + backward
-    def loss_grads(self, grads):
-        """Needs a preceding forward(keep=True).  `grads`: {name: zeroed tensor} receiving d loss / d parameter.
-        Returns (loss 0-dim tensor, terms [17])."""
-        o, lib, s, v = self.ops, self.lib, self._stream(), self.sv
-        self.g = grads
-        H, W = v["HW"]
+    def _terms(self, v, H, W):
+        """Fused loss terms + direct gradients from the tensors in `v` (loss.py:23-78).  Returns (loss[1], terms[17], grads dict)."""
+        o, lib, s = self.ops, self.lib, self._stream()
         h, w = H // 2, W // 2
         HW, hw = H * W, h * w
         terms = self._new(17)
@@ -262,7 +259,7 @@ class Engine:
         lib.call("zt_partial_reduce_f32", p2.data_ptr() + 32, nb2, 10, 2, terms.data_ptr() + 56, 0, None, s)
         # ---- full-resolution terms
         DH2, VH2 = o.localvar_fwd(v["H2"])
-        DN, VN = o.localvar_fwd(v["H3"].contiguous() if not v["H3"].is_contiguous() else v["H3"], v["H2"])
+        DN, VN = o.localvar_fwd(v["H3"], v["H2"])
         dH3b, ds3, gV = self._new(1, 3, H, W), self._new(1, 3, H, W), self._new(1, 3, H, W)
         nb3 = (3 * HW + 255) // 256
         p3 = self._new(nb3, 3)
@@ -271,6 +268,22 @@ class Engine:
         lib.call("zt_partial_reduce_f32", p3.data_ptr() + 8, nb3, 3, 1, terms.data_ptr() + 64, 0, None, s)
         loss = self._new(1)
         o.partial_reduce(terms, 17, 1, 1, out=loss)
+        g = dict(ds2=ds2, dLp1=dLp1, dLp2=dLp2, dden1=dden1, dden2=dden2, dH3p=dH3p, dH4p=dH4p, dH3d1=dH3d1, dH3d2=dH3d2,
+                 u1=u1, u2=u2, DH2=DH2, DN=DN, dH3b=dH3b, ds3=ds3, gV=gV)
+        return loss, terms, g
+
+    def loss_grads(self, grads):
+        """Needs a preceding forward(keep=True).  `grads`: {name: zeroed tensor} receiving d loss / d parameter.
+        Returns (loss 0-dim tensor, terms [17])."""
+        o, lib, s, v = self.ops, self.lib, self._stream(), self.sv
+        self.g = grads
+        H, W = v["HW"]
+        h, w = H // 2, W // 2
+        HW, hw = H * W, h * w
+        loss, terms, t = self._terms(v, H, W)
+        ds2, dLp1, dLp2, dden1, dden2 = t["ds2"], t["dLp1"], t["dLp2"], t["dden1"], t["dden2"]
+        dH3p, dH4p, dH3d1, dH3d2, u1, u2 = t["dH3p"], t["dH4p"], t["dH3d1"], t["dH3d2"], t["u1"], t["u2"]
+        DH2, DN, dH3b, ds3, gV = t["DH2"], t["DN"], t["dH3b"], t["ds3"], t["gV"]
         # ---- backward: into H3 / H2
         o.box5_reflect_adj(u1, -1.0, out=dH3d1)
         o.box5_reflect_adj(u2, -1.0, out=dH3d2)
@@ -300,3 +313,38 @@ class Engine:
         self._denoise_bwd(D1, "D1b", dn12, 3, False)
         self._denoise_bwd(D1, "D1c", dn, 3, False)
         return loss, terms
+
+
+def _c(t):
+    return t.detach().contiguous().float()
+
+
+def loss_value(ops, is_WB, inp, Lp1, Lp2, L2, s2, s21, s22, H2, H11, H12, H3, s3, H3p, H4p, m_h, H2b, H3b):
+    """LossFunction.forward (loss.py:23-78) on explicit tensors (the drop-in `loss.LossFunction`).  -> (loss[1], terms[17])."""
+    eng = Engine(ops, {"_": _c(inp)}, {}, is_WB=is_WB, device=inp.device)
+    _, _, H, W = inp.shape
+    h, w = H // 2, W // 2
+    lib, s = ops.lib, eng._stream()
+    x, L11, L12, Lq11, Lq12 = eng._new(1, 3, H, W), eng._new(1, 3, h, w), eng._new(1, 3, h, w), eng._new(1, 3, h, w), eng._new(1, 3, h, w)
+    lib.call("zt_prep_input_f32", _c(inp), x, L11, L12, Lq11, Lq12, H, W, s)
+    den1, den2 = ops.pair_down(_c(L2))
+    H3d1, H3d2 = ops.pair_down(_c(H3))
+    v = dict(L2=_c(L2), s2=_c(s2), Lq11=Lq11, Lq12=Lq12, Lp1=_c(Lp1), Lp2=_c(Lp2), den1=den1, den2=den2, H3p=_c(H3p), H4p=_c(H4p),
+             H11=_c(H11), s21=_c(s21), H12=_c(H12), s22=_c(s22), H3d1=H3d1, H3d2=H3d2, m_h=_c(m_h), H2=_c(H2), H3=_c(H3),
+             H2b=_c(H2b), H3b=_c(H3b), s3=_c(s3))
+    loss, terms, _ = eng._terms(v, H, W)
+    return loss, terms
+
+
+def smooth_tv_values(ops, L2, s2):
+    """(SmoothLoss(L2, s2), L_TV(s2)) of loss.py:139-152, 173-311 (un-weighted), through the fused s2-term kernel."""
+    eng = Engine(ops, {"_": _c(L2)}, {}, device=L2.device)
+    _, _, H, W = L2.shape
+    L2c, s2c = _c(L2), _c(s2)
+    Y = ops.ycc_flat(L2c)
+    scal = torch.ones(8, dtype=torch.float32, device=L2.device)
+    nb1 = ((W + 63) // 64) * ((H + 3) // 4)
+    p1, ds2, out = eng._new(nb1, 4), eng._new(1, 3, H, W), eng._new(4)
+    ops.lib.call("zt_loss_s2_f32", L2c, s2c, Y, scal, H, W, ds2, p1, eng._stream())
+    ops.partial_reduce(p1, nb1, 4, 4, out=out)
+    return out[2] / 5.0, out[3] / 1600.0

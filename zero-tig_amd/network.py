@@ -128,6 +128,24 @@ class RAFT(_Holder):                                       # raft.py:23-48
         self.fnet = _BasicEncoder(256, "instance")
         self.cnet = _BasicEncoder(256, "batch")
         self.update_block = _UpdateBlock()
+        self.__dict__["_plan_cache"] = None
+
+    def forward(self, image1, image2, iters=12, test_mode=True, ops=None):
+        """raft.py:77-130: frames in [0,255], [1,3,h,w] -> (flow_low [1,2,h8,w8], flow_up [1,2,Hp,Wp] at the padded size)."""
+        dev = image1.device
+        key = (dev, self.fnet.conv1.weight.data_ptr())
+        if self._plan_cache is None or self._plan_cache[0] != key:
+            ops = ops if ops is not None else Ops(get_lib())
+            rw = {"raft." + k: v.data for k, v in self.state_dict().items()}
+            self.__dict__["_plan_cache"] = (key, RaftPlan(ops, rw, dev), ops)
+        _, plan, ops = self._plan_cache
+        _, _, h, w = image1.shape
+        Hp, Wp = (h + 7) // 8 * 8, (w + 7) // 8 * 8
+        x2 = torch.empty((2, Hp, Wp, 4), dtype=torch.float32, device=dev)
+        from .lib import current_stream
+        ops.lib.call("zt_raft_pack_pair_f32", image1.detach().contiguous().float(), image2.detach().contiguous().float(), x2, h, w,
+                     Hp, Wp, current_stream(dev))
+        return plan.run(x2, iters=iters)
 
 
 TRAINABLE = ("enhance.in_conv.0", "enhance.conv.0", "enhance.conv.1", "enhance.out_conv.0", "denoise_1.conv1",
