@@ -7,6 +7,7 @@
  *     workspaces) and keeps it alive until the stream reaches the next op; nothing here allocates or synchronises;
  *   - every function enqueues on `stream` (hipStream_t passed as void*) and returns 0, a hipError_t, or 1001
  *     (invalid argument); the Python host raises RuntimeError on non-zero (zero-tig_amd/lib.py);
+ *   - `dt` arguments select the storage type of nhwc activation buffers: 0 = fp32, 1 = bf16 (raw 16-bit, round-to-nearest-even)
  *   - "planar" = [C][H][W] fp32 (the reference's NCHW with N == 1); "nhwc" = [N][H][W][ld] fp32 with an explicit
  *     channel stride `ld` so channel slices of wider buffers can be addressed without copies.
  */
@@ -73,7 +74,7 @@ int zt_repack_conv_weight_f32(const float* src, float* dst, int Cout, int Cin, i
 /* ---- normalisation (zt_norm.hip): nn.BatchNorm2d of model.py:62 (train mode, shared 3x), eval BatchNorm /
  * InstanceNorm of model/RAFT/extractor.py:117-191.  All on nhwc buffers, C % 4 == 0. ------------------------------- */
 /* per-(n,c) partial sums over HW pixels: partial[((n*nblk+blk)*2 + {0 sum, 1 sum of squares})*C + c] */
-int zt_chan_stats_nhwc_f32(const float* x, int ldx, int N, int HW, int C, int nblk, float* partial, zt_stream_t stream);
+int zt_chan_stats_nhwc(const void* x, int dt, int ldx, int N, int HW, int C, int nblk, float* partial, zt_stream_t stream);
 /* mode 0 instance norm (scale = rstd, shift = -mean*rstd); 1 train BN (batch stats, running stats += momentum update with
  * unbiased variance, *num_batches_tracked += 1); 2 eval BN (running stats).  Outputs scale/shift (and mean/rstd) [N][C]. */
 int zt_norm_finalize_f32(const float* partial, int nblk, int N, int C, long long count, float eps, int mode,
@@ -81,16 +82,16 @@ int zt_norm_finalize_f32(const float* partial, int nblk, int N, int C, long long
                          long long* num_batches_tracked, float momentum, float* scale, float* shift, float* mean_out,
                          float* rstd_out, zt_stream_t stream);
 /* y = [outer_relu]([res +] [inner_relu](x*scale + shift)) */
-int zt_norm_apply_nhwc_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldres,
-                           float* y, int ldy, int N, int HW, int C, int inner_relu, int outer_relu, zt_stream_t stream);
+int zt_norm_apply_nhwc(const void* x, int dt, int ldx, const float* scale, const float* shift, const void* res, int ldres,
+                           void* y, int ldy, int N, int HW, int C, int inner_relu, int outer_relu, zt_stream_t stream);
 /* backward of y = ReLU(BN_train(z)): stage 1 partial sums of dyh = dy*[bn>0] and dyh*zhat; generic partial reduction;
  * stage 2 dz = gamma*rstd*(dyh - mean(dyh) - zhat*mean(dyh*zhat)) with sums = [sum dyh (C) | sum dyh*zhat (C)] */
-int zt_bn_bwd_reduce_f32(const float* dy, int lddy, const float* z, int ldz, const float* scale, const float* shift,
+int zt_bn_bwd_reduce(const void* dy, int dt, int lddy, const void* z, int ldz, const float* scale, const float* shift,
                          const float* mean, const float* rstd, int HW, int C, int nblk, float* partial, zt_stream_t stream);
 int zt_partial_reduce_f32(const float* partial, int nblk, int stride, int n, float* out, int accumulate, float* out2,
                           zt_stream_t stream);
-int zt_bn_bwd_apply_f32(const float* dy, int lddy, const float* z, int ldz, const float* scale, const float* shift,
-                        const float* mean, const float* rstd, const float* sums, float* dz, int lddz, int HW, int C,
+int zt_bn_bwd_apply(const void* dy, int dt, int lddy, const void* z, int ldz, const float* scale, const float* shift,
+                        const float* mean, const float* rstd, const float* sums, void* dz, int lddz, int HW, int C,
                         zt_stream_t stream);
 
 
@@ -98,7 +99,7 @@ int zt_bn_bwd_apply_f32(const float* dy, int lddy, const float* z, int ldz, cons
 /* model.py:145-148, loss.py:25,51: x = inp+1e-4; (L11,L12) = pair_downsampler(x); (Lq11,Lq12) = pair_downsampler(inp+1e-9) */
 int zt_prep_input_f32(const float* inp, float* x, float* L11, float* L12, float* Lq11, float* Lq12, int H, int W, zt_stream_t stream);
 /* torch.cat([...],1) of up to four planar tensors into one nhwc buffer (remaining channels zero) (model.py:168,179,184,189) */
-int zt_pack_nhwc_f32(float* dst, int ld, long long HW, const float* s0, int c0, const float* s1, int c1, const float* s2, int c2,
+int zt_pack_nhwc(void* dst, int dt, int ld, long long HW, const float* s0, int c0, const float* s1, int c1, const float* s2, int c2,
                      const float* s3, int c3, zt_stream_t stream);
 /* model.py:149-152 + loss.py:54: L2 = clamp(x-n,1e-4,1); L_pred1/2 = L11/12 - n11/12; (den1,den2) = pair_downsampler(L2) */
 int zt_d1_tail_f32(const float* x, const float* n, const float* L11, const float* n11, const float* L12, const float* n12,
@@ -109,17 +110,17 @@ int zt_post_enh_f32(const float* x, const float* s2, const float* L2, const floa
 /* model.py:179-192: (outA|outB) = clamp(cat[A,B] - r, 1e-4, 1), r planar 6ch */
 int zt_clamp_sub6_f32(const float* A, const float* B, const float* r, float* outA, float* outB, long long HW, zt_stream_t stream);
 /* its backward into the nhwc gradient of r */
-int zt_clamp_sub6_bwd_f32(const float* A, const float* B, const float* r, const float* gA, const float* gB, float* dr, int ld,
+int zt_clamp_sub6_bwd(const float* A, const float* B, const float* r, const float* gA, const float* gB, void* dr, int dt, int ld,
                           long long HW, zt_stream_t stream);
 /* all gradient paths into s2 (H2, H11/H12, pair_downsampler, Denoise_2 inputs, direct loss terms) -> Enhancer output-layer gradient (nhwc) */
-int zt_post_enh_bwd_f32(const float* x, const float* s2, const float* L11, const float* L12, const float* s21, const float* s22,
+int zt_post_enh_bwd(const float* x, const float* s2, const float* L11, const float* L12, const float* s21, const float* s22,
                         const float* dIn5, const float* dH2x, const float* dIn3, const float* dIn4, const float* ds2_direct,
-                        float* dO, int ld, float* ds2_total, int H, int W, zt_stream_t stream);
+                        void* dO, int dt, int ld, float* ds2_total, int H, int W, zt_stream_t stream);
 /* gradients entering the three Denoise_1 invocations (nhwc) */
-int zt_d1_bwd_prep_f32(const float* x, const float* n, const float* dLp1, const float* dLp2, const float* dden1,
-                       const float* dden2, float* dn, float* dn11, float* dn12, int ld, int H, int W, zt_stream_t stream);
+int zt_d1_bwd_prep(const float* x, const float* n, const float* dLp1, const float* dLp2, const float* dden1,
+                       const float* dden2, void* dn, void* dn11, void* dn12, int dt, int ld, int H, int W, zt_stream_t stream);
 /* ReLU backward on nhwc buffers: out = g * [a > 0] */
-int zt_relu_mask_nhwc_f32(const float* g, int ldg, const float* a, int lda, float* out, int ldo, long long npix, int C, zt_stream_t stream);
+int zt_relu_mask_nhwc(const void* g, int dt, int ldg, const void* a, int lda, void* out, int ldo, long long npix, int C, zt_stream_t stream);
 /* element-wise helpers of Finetunemodel.forward (model.py:313-316,327-328): mode 0 a+p0; 1 clamp(a-b,p0,p1); 2 clamp(a/b,p0,p1) */
 int zt_ew_f32(const float* a, const float* b, float* out, int mode, float p0, float p1, long long n, zt_stream_t stream);
 /* utils.py:228 overlap_tensor = 0.5*warped + 0.5*img2: out = alpha*a + beta*b */
@@ -174,6 +175,24 @@ int zt_convex_upsample_f32(const float* f4, int ldf, const float* mask, int ldm,
 int zt_clip_adam_f32(float* p, const float* g, float* m, float* v, long long n, float* partial, int nblk, float gscale,
                      float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,
                      float* gnorm_out, zt_stream_t stream);
+
+
+/* ---- hardware self-test probes (zt_probe.hip): pin the test emulator's model of gfx950 instructions to the chip ----- */
+/* ds_read_b64_tr_b16 on a [16][64] image of 16-bit codes: out[lane*4+q]; bf16 MFMA 16x16x32: D[16][16] = A[16][32] B[32][16] */
+int zt_probe_tr16(const unsigned short* img, unsigned short* out, int col0, zt_stream_t stream);
+int zt_probe_mfma_bf16(const unsigned short* A, const unsigned short* B, float* D, zt_stream_t stream);
+
+
+/* ---- bf16 throughput mode of the convolution family: x / y / aux / dz are bf16 nhwc (channel strides multiples of 8), w is
+ * bf16 [tap][CoutP][ldk] (input channel fastest), accumulation fp32; y may instead be fp32 planar (thin output layers).
+ * Supported (KH,KW,stride): (3,3,1), (1,1,1) -- the enhancement / denoising nets.  Same act / alpha / epi semantics. */
+int zt_conv2d_nhwc_bf16(const void* x, int ldx, int N, int H, int W, int Cin, const void* w, int CoutP, int ldk, const float* bias,
+                        void* y, int ldy, int out_f32_planar, int Cout, int KH, int KW, int stride, int padH, int padW, int act,
+                        float alpha, const void* aux, int ldaux, int epi, zt_stream_t stream);
+int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout, int KH, int KW,
+                              float* slab, size_t slab_bytes, float* grad_w, int accumulate, zt_stream_t stream);
+int zt_repack_conv_weight_bf16(const float* src, void* dst, int Cout, int Cin, int KH, int KW, int CoutP, int ldk,
+                               int transpose_flip, zt_stream_t stream);
 
 #ifdef __cplusplus
 }

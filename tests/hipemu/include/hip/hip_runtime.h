@@ -222,8 +222,12 @@ static inline zt_emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float 
 
 static inline float zt_emu_bf16_to_f32(short s) { uint32_t u = ((uint32_t)(uint16_t)s) << 16; float f; memcpy(&f, &u, 4); return f; }
 
+typedef __bf16 zt_emu_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short zt_emu_s16x4 __attribute__((ext_vector_type(4)));
+
 // v_mfma_f32_16x16x32_bf16: A[row=l&15][k=8*(l>>4)+j], B[k=8*(l>>4)+j][col=l&15]; D as 16x16x4
-static inline zt_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(zt_emu_s16x8 a, zt_emu_s16x8 b, zt_emu_f32x4 c, int, int, int) {
+static inline zt_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(zt_emu_bf16x8 a_, zt_emu_bf16x8 b_, zt_emu_f32x4 c, int, int, int) {
+  zt_emu_s16x8 a = __builtin_bit_cast(zt_emu_s16x8, a_), b = __builtin_bit_cast(zt_emu_s16x8, b_);
   emu::Wave& w = emu::my_wave();
   int l = emu::my_lane();
   for (int j = 0; j < 8; ++j) {
@@ -249,8 +253,29 @@ static inline zt_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(zt_emu_s16x8 
   return d;
 }
 
+// ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per 16-lane group, lane 4q+p supplies the address of row q, columns
+// 4p..4p+3; lane i receives column i of the 4 rows (row q in element q).
+static inline zt_emu_s16x4 zt_emu_ds_read_tr16(const void* p) {
+  emu::Wave& w = emu::my_wave();
+  int l = emu::my_lane();
+  uint64_t addr = (uint64_t)(uintptr_t)p;
+  memcpy(&w.buf[l][0], &addr, 8);
+  emu::wave_sync();
+  zt_emu_s16x4 r;
+  int g = l & ~15, i = l & 15;
+  for (int q = 0; q < 4; ++q) {
+    uint64_t a;
+    memcpy(&a, &w.buf[g + 4 * q + (i >> 2)][0], 8);
+    r[q] = ((const short*)(uintptr_t)a)[i & 3];
+  }
+  emu::wave_sync();
+  return r;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) zt_emu_ds_read_tr16((const void*)(p))
+
 // v_mfma_f32_32x32x16_bf16: A[row=l&31][k=8*(l>>5)+j], B[k][col=l&31]; D as 32x32x2
-static inline zt_emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(zt_emu_s16x8 a, zt_emu_s16x8 b, zt_emu_f32x16 c, int, int, int) {
+static inline zt_emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(zt_emu_bf16x8 a_, zt_emu_bf16x8 b_, zt_emu_f32x16 c, int, int, int) {
+  zt_emu_s16x8 a = __builtin_bit_cast(zt_emu_s16x8, a_), b = __builtin_bit_cast(zt_emu_s16x8, b_);
   emu::Wave& w = emu::my_wave();
   int l = emu::my_lane();
   for (int j = 0; j < 8; ++j) {

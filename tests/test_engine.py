@@ -65,13 +65,13 @@ def test_newseq_forward_loss_grads(backend, synth, oracle, name, wb):
             assert rel_l2(gr, ref) < 1e-3, (n, rel_l2(gr, ref))
 
 
-def _network(ops, dev, synth, seed, dataset="RLV", of_scale=1, cls="Network", pretrain=None):
+def _network(ops, dev, synth, seed, dataset="RLV", of_scale=1, cls="Network", pretrain=None, precision="fp32"):
     import argparse
     net_mod = importlib.import_module("zero-tig_amd.network")
     args = argparse.Namespace(dataset=dataset, of_scale=of_scale)
     if pretrain is not None:
         args.model_pretrain = pretrain
-    net = getattr(net_mod, cls)(args, ops=ops)
+    net = getattr(net_mod, cls)(args, ops=ops, precision=precision)
     if pretrain is None:
         st = synth.make_state(seed)
         sd = net.state_dict()
@@ -180,3 +180,26 @@ def test_finetune_golden(backend, synth, tmp_path):
             tol = 2e-5 if t == 0 else 2e-4
             for nm, o in (("H2", H2), ("H3", H3), ("s3", s3)):
                 assert float(np.abs(o.cpu().numpy() - g["%s_%d" % (nm, t)]).max()) < tol, (nm, t)
+
+
+def test_bf16_mode_psnr_gate(backend, synth, oracle):
+    """Throughput mode (bf16 activations/weights, fp32 accumulate): enhanced-frame PSNR within 0.01 dB of the reference
+    (evals.py:83-85 definition vs the synthetic clean frame), loss and gradients close to the fp32 reference values."""
+    ops, dev, bname = backend
+    g = load_golden("g12_newseq_rlv_48x64")
+    H, W, seed, _ = [int(v) for v in g["meta"]]
+    x = frames(synth, 1, H, W)[0]
+    net = _network(ops, dev, synth, seed, of_scale=3, precision="bf16").train()
+    net.is_new_seq = True
+    loss = net._loss(x.to(dev))
+    loss.backward()
+    H3 = net.last_H3.cpu()
+    ref_H3 = torch.from_numpy(g["out13"])
+    clean = torch.from_numpy(synth.clean_frame(0, H, W)).float()[None]
+    d_psnr = abs(oracle.psnr_u8(H3, clean) - oracle.psnr_u8(ref_H3, clean))
+    assert d_psnr <= 0.01, d_psnr
+    assert oracle.psnr_u8(H3, ref_H3) > 45.0
+    assert abs(float(loss) - float(g["loss"])) <= 1e-2 * abs(float(g["loss"]))
+    for n, p in net.named_parameters():
+        if p.requires_grad and not n.startswith("enhance.blocks") and n != "enhance.conv.0.bias":
+            assert rel_l2(p.grad, g["grad:" + n]) < 6e-2, (n, rel_l2(p.grad, g["grad:" + n]))

@@ -299,3 +299,92 @@ def test_raft_update_step_golden(backend, oracle, synth):
     up = torch.empty(1, 2, 8 * h, 8 * w, device=dev)
     ops.lib.call("zt_convex_upsample_f32", f4.to(dev), 4, _nhwc(mask).to(dev), 576, up, None, h, w, None if dev.type == "cpu" else torch.cuda.current_stream().cuda_stream)
     assert maxerr(up, torch.from_numpy(g["ub_up"])) < 1e-4
+
+
+def test_probe_tr16_and_bf16_mfma(backend):
+    """gfx950 instruction semantics the bf16 kernels rely on, checked on whichever back-end runs (emulator model == chip)."""
+    ops, dev, _ = backend
+    s = None if dev.type == "cpu" else torch.cuda.current_stream().cuda_stream
+    img = torch.arange(16 * 64, dtype=torch.int32).to(torch.int16).view(16, 64)
+    for col0 in (0, 16, 44):
+        out = torch.zeros(64 * 4, dtype=torch.int16, device=dev)
+        ops.lib.call("zt_probe_tr16", img.to(dev), out, col0, s)
+        got = out.cpu().view(64, 4)
+        for l in range(64):
+            g, i = l // 16, l % 16
+            for q in range(4):     # lane i of group g receives column i of block row q
+                assert int(got[l, q]) == int(img[4 * g + q, col0 + i]), (col0, l, q)
+    gen = torch.Generator().manual_seed(3)
+    A = torch.randn(16, 32, generator=gen).bfloat16()
+    B = torch.randn(32, 16, generator=gen).bfloat16()
+    D = torch.zeros(16, 16, device=dev)
+    ops.lib.call("zt_probe_mfma_bf16", A.view(torch.int16).to(dev), B.view(torch.int16).to(dev), D, s)
+    assert maxerr(D, A.float() @ B.float()) < 1e-4
+
+
+def _nhwc_bf16(t, ld):
+    n = _nhwc(t, ld)
+    return n.bfloat16().contiguous()
+
+
+BF16_CONV = [(3, 48, 3, 8, "lrelu"), (48, 48, 3, 48, "lrelu"), (64, 64, 3, 64, "relu"), (64, 3, 3, 64, "sigmoid_clamp"),
+             (48, 6, 1, 48, None), (9, 64, 3, 16, "relu"), (12, 48, 3, 16, None)]
+
+
+@pytest.mark.parametrize("case", BF16_CONV, ids=lambda c: "c%d-%d_k%d" % c[:3])
+def test_conv_bf16(backend, case):
+    import torch.nn.functional as F
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    Cin, Cout, K, ld, act = case
+    g = torch.Generator().manual_seed(Cin * 17 + Cout)
+    H, W = 7, 37
+    x = torch.randn(1, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5)
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w.bfloat16().float(), b, padding=K // 2)
+    ref = {None: lambda t: t, "relu": torch.relu, "lrelu": lambda t: F.leaky_relu(t, 0.2),
+           "sigmoid_clamp": lambda t: torch.clamp(torch.sigmoid(t), 1e-4, 1)}[act](ref)
+    xd = _nhwc_bf16(x, ld).to(dev)
+    wd = ops.repack_weight_bf16(w.to(dev))
+    y = ops.conv2d_bf16(CV(xd, 0, Cin), wd, b.to(dev), Cout, K, K, (K // 2, K // 2), act)
+    got = y.float().cpu()[..., :Cout].permute(0, 3, 1, 2)
+    assert float(((got - ref).abs() - ref.abs() * 2 ** -8).max()) < 2e-3
+    if Cout <= 6:
+        yp = ops.conv2d_bf16(CV(xd, 0, Cin), wd, b.to(dev), Cout, K, K, (K // 2, K // 2), act, out_planar=True)
+        assert maxerr(yp, ref) < 2e-4            # fp32 planar output: only the bf16 inputs differ from the fp32 reference
+    # dgrad operator with the LeakyReLU-mask epilogue
+    if Cin >= 48 and Cout >= 48:
+        dz = torch.randn(1, Cout, H, W, generator=g).bfloat16().float()
+        aux = torch.randn(1, Cin, H, W, generator=g).bfloat16().float()
+        xg = x.clone().requires_grad_(True)
+        (F.conv2d(xg, w.bfloat16().float(), None, padding=K // 2) * dz).sum().backward()
+        refg = xg.grad * torch.where(aux > 0, 1.0, 0.2)
+        wt = ops.repack_weight_bf16(w.to(dev), transpose_flip=True)
+        dx = ops.conv2d_bf16(CV(_nhwc_bf16(dz, Cout).to(dev)), wt, None, Cin, K, K, (K // 2, K // 2), None,
+                             aux=_nhwc_bf16(aux, Cin).to(dev), epi=1)
+        gotg = dx.float().cpu().permute(0, 3, 1, 2)
+        assert float(((gotg - refg).abs() - refg.abs() * 2 ** -8).max()) < 2e-3
+
+
+BF16_WGRAD = [(3, 48, 3, 8, 48), (48, 48, 3, 48, 48), (48, 3, 1, 48, 8), (9, 64, 3, 16, 64), (64, 64, 3, 64, 64), (64, 3, 3, 64, 8),
+              (12, 48, 3, 16, 48), (48, 6, 1, 48, 8)]
+
+
+@pytest.mark.parametrize("case", BF16_WGRAD, ids=lambda c: "c%d-%d_k%d" % c[:3])
+def test_conv_wgrad_bf16(backend, case):
+    import torch.nn.functional as F
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    Cin, Cout, K, ldx, lddz = case
+    g = torch.Generator().manual_seed(Cin + 13 * Cout)
+    H, W = 9, 41
+    x = torch.randn(1, Cin, H, W, generator=g).bfloat16().float()
+    dz = torch.randn(1, Cout, H, W, generator=g).bfloat16().float()
+    w = torch.zeros(Cout, Cin, K, K, requires_grad=True)
+    (F.conv2d(x, w, None, padding=K // 2) * dz).sum().backward()
+    gw = torch.full((Cout, Cin, K, K), 3.0, device=dev)
+    ops.conv2d_wgrad_bf16(CV(_nhwc_bf16(x, ldx).to(dev), 0, Cin), CV(_nhwc_bf16(dz, lddz).to(dev), 0, Cout), Cout, K, K, gw)
+    assert maxerr(gw, w.grad) < 2e-3 * float(w.grad.abs().max()), maxerr(gw, w.grad)

@@ -65,3 +65,60 @@ __device__ __forceinline__ int zt_reflect(int i, int n) {
   if (i >= n) i = 2 * (n - 1) - i;
   return i;
 }
+
+// ---- bf16 storage helpers (activations / weights of the throughput mode are bf16 in HBM, math is fp32) -------------
+typedef unsigned short zt_bf16;                                        // raw bits
+typedef short zt_s16x4 __attribute__((ext_vector_type(4)));
+typedef short zt_s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 zt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float zt_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float zt_bf2f(zt_bf16 h) {
+  unsigned u = ((unsigned)h) << 16;
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+__device__ __forceinline__ zt_bf16 zt_f2bf(float f) {                   // round to nearest even (finite inputs)
+  unsigned u;
+  __builtin_memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (zt_bf16)(u >> 16);
+}
+
+// element access that is generic over the NHWC storage type
+template <typename T> struct ZtIO;
+template <> struct ZtIO<float> {
+  static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ZtIO<zt_bf16> {
+  static __device__ __forceinline__ float4 ld4(const zt_bf16* p) {
+    uint2 r = *reinterpret_cast<const uint2*>(p);
+    float4 v;
+    unsigned a = r.x << 16, b = r.x & 0xFFFF0000u, c = r.y << 16, d = r.y & 0xFFFF0000u;
+    __builtin_memcpy(&v.x, &a, 4); __builtin_memcpy(&v.y, &b, 4); __builtin_memcpy(&v.z, &c, 4); __builtin_memcpy(&v.w, &d, 4);
+    return v;
+  }
+  static __device__ __forceinline__ void st4(zt_bf16* p, float4 v) {
+    uint2 r;
+    r.x = (unsigned)zt_f2bf(v.x) | ((unsigned)zt_f2bf(v.y) << 16);
+    r.y = (unsigned)zt_f2bf(v.z) | ((unsigned)zt_f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+  }
+  static __device__ __forceinline__ float ld(const zt_bf16* p) { return zt_bf2f(*p); }
+  static __device__ __forceinline__ void st(zt_bf16* p, float v) { *p = zt_f2bf(v); }
+};
+
+// D = A(16x32 bf16) * B(32x16 bf16) + C: lane l holds A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15], j = 0..7
+__device__ __forceinline__ zt_f32x4 zt_mfma_bf16(zt_s16x8 a, zt_s16x8 b, zt_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(zt_bf16x8, a), __builtin_bit_cast(zt_bf16x8, b), c, 0, 0, 0);
+}
+
+// gfx950 transposing LDS read: per 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a 4x16 block of
+// 16-bit elements; lane i receives column i of the 4 rows (row q in element q).  EXEC must be all ones.
+__device__ __forceinline__ zt_s16x4 zt_lds_read_tr16(const zt_bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) zt_s16x4*)p);
+}

@@ -341,6 +341,288 @@ int launch_wgrad(const WgradArgs& a, int CT, int NT, int nblk, hipStream_t strea
   return ZT_EINVAL;
 }
 
+// =====================================================================================================================
+// bf16 throughput mode: activations and weights are bf16 in HBM, accumulation fp32 (v_mfma_f32_16x16x32_bf16, 16x the
+// fp32 matrix rate).  Same tiling as the fp32 kernels; the K step is 32 channels, both operands are read from LDS with
+// one ds_read_b128 per fragment ([pixel][40] / [cout][40] bf16 rows: 80-byte pitch -> conflict free).
+// Weights: [tap][CoutP16][ldk] with the input channel fastest (ldk = Cin rounded to 8, zero padded).
+// =====================================================================================================================
+struct ConvArgsH {
+  const zt_bf16* x;
+  const zt_bf16* w;
+  const float* bias;
+  const zt_bf16* aux;
+  void* y;
+  int N, H, W, Cin, ldx;
+  int Ho, Wo, Cout, CoutP, ldk, ldy, ldaux;
+  int padH, padW;
+  int act, epi, out_f32_planar;
+  float alpha;
+  int tilesX, tilesY;
+};
+
+constexpr int HCK = 32, HCKP = 40;
+
+template <int KH, int KW, int S, int NT>
+__global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
+  constexpr int IR = (TH - 1) * S + KH, IC = (TW - 1) * S + KW;
+  __shared__ __attribute__((aligned(16))) zt_bf16 xs[IR * IC * HCKP];
+  __shared__ __attribute__((aligned(16))) zt_bf16 ws[KW * NT * 16 * HCKP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x;
+  const int tx = t % a.tilesX;
+  t /= a.tilesX;
+  const int ty = t % a.tilesY;
+  const int n = t / a.tilesY;
+  const int co0 = blockIdx.y * (NT * 16);
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int gy0 = oy0 * S - a.padH, gx0 = ox0 * S - a.padW;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  zt_f32x4 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[m][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int c0 = 0; c0 < a.Cin; c0 += HCK) {
+    __syncthreads();
+    for (int e = tid; e < IR * IC * 4; e += 256) {
+      int p = e >> 2, q = e & 3;
+      int iy = p / IC, ixx = p - iy * IC;
+      int gy = gy0 + iy, gx = gx0 + ixx;
+      int c = c0 + q * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Cin) {
+        const zt_bf16* g = a.x + ((size_t)(n * a.H + gy) * a.W + gx) * a.ldx + c;
+        v = *reinterpret_cast<const uint4*>(g);
+        if (c + 8 > a.Cin) {            // ragged tail: keep only the valid channels
+          zt_bf16 tmp[8];
+          __builtin_memcpy(tmp, &v, 16);
+          for (int j = 0; j < 8; ++j)
+            if (c + j >= a.Cin) tmp[j] = 0;
+          __builtin_memcpy(&v, tmp, 16);
+        }
+      }
+      *reinterpret_cast<uint4*>(xs + p * HCKP + q * 8) = v;
+    }
+#pragma unroll 1
+    for (int ky = 0; ky < KH; ++ky) {
+      for (int e = tid; e < KW * NT * 16 * 4; e += 256) {
+        int q = e & 3;
+        int r = e >> 2;
+        int co = r % (NT * 16), kx = r / (NT * 16);
+        int c = c0 + q * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (c < a.ldk && co0 + co < a.CoutP)
+          v = *reinterpret_cast<const uint4*>(a.w + ((size_t)(ky * KW + kx) * a.CoutP + co0 + co) * a.ldk + c);
+        *reinterpret_cast<uint4*>(ws + (kx * NT * 16 + co) * HCKP + q * 8) = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) {
+        zt_s16x8 av[2], bv[NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          av[m] = *reinterpret_cast<const zt_s16x8*>(xs + ((wave * S + ky) * IC + (m * 16 + l15) * S + kx) * HCKP + 8 * l4);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) bv[q] = *reinterpret_cast<const zt_s16x8*>(ws + (kx * NT * 16 + q * 16 + l15) * HCKP + 8 * l4);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(av[m], bv[q], acc[m][q]);
+      }
+      __syncthreads();
+    }
+  }
+
+  const int oy = oy0 + wave;
+  if (oy >= a.Ho) return;
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    const int co = co0 + q * 16 + l15;
+    if (co >= a.Cout) continue;
+    const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ox = ox0 + m * 16 + l4 * 4 + j;
+        if (ox >= a.Wo) continue;
+        float v = apply_act(a.alpha * (acc[m][q][j] + b), a.act);
+        const size_t pix = (size_t)(n * a.Ho + oy) * a.Wo + ox;
+        if (a.epi) {
+          float u = zt_bf2f(a.aux[pix * a.ldaux + co]);
+          if (a.epi == 1) v *= (u > 0.f ? 1.f : 0.2f);
+          else if (a.epi == 2) v *= (u > 0.f ? 1.f : 0.f);
+          else v += u;
+        }
+        if (a.out_f32_planar) ((float*)a.y)[((size_t)n * a.Cout + co) * a.ldy + (size_t)oy * a.Wo + ox] = v;
+        else ((zt_bf16*)a.y)[pix * a.ldy + co] = zt_f2bf(v);
+      }
+    }
+  }
+}
+
+template <int KH, int KW, int S>
+int launch_conv_h(const ConvArgsH& a, int NT, dim3 grid_base, hipStream_t stream) {
+  dim3 block(256);
+  int c16 = (a.Cout + 15) / 16;
+  dim3 grid(grid_base.x, (c16 + NT - 1) / NT);
+  switch (NT) {
+    case 1: hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, 1>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, 2>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, 3>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, 4>), grid, block, 0, stream, a); break;
+  }
+  return 0;
+}
+
+// ---- bf16 weight gradient.  K = pixels: the MFMA needs 8 consecutive PIXELS per lane for one channel, i.e. the
+// transpose of the NHWC tile; ds_read_b64_tr_b16 delivers exactly that from a [pixel][channel] LDS image, so staging is a
+// plain 16-byte copy and tap shifts are row shifts (alignment preserved).
+struct WgradArgsH {
+  const zt_bf16* x;
+  const zt_bf16* dz;
+  float* slab;
+  int H, W, Cin, ldx, Cout, lddz;
+  int tilesX, ntiles;
+};
+
+constexpr int HTH = 4, HTW = 32;
+
+template <int KH, int KW, int CT, int NT>
+__global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
+  constexpr int IR = HTH + KH - 1, IC = HTW + KW - 1;
+  constexpr int CIP = CT * 16 + 8, COP = NT * 16 + 8;
+  constexpr int NPAIR = KH * KW * CT;
+  constexpr int PPW = (NPAIR + 3) / 4;
+  constexpr int padH = (KH - 1) / 2, padW = (KW - 1) / 2;
+  __shared__ __attribute__((aligned(16))) zt_bf16 xs[IR * IC * CIP];
+  __shared__ __attribute__((aligned(16))) zt_bf16 zs[HTH * HTW * COP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g8 = (lane >> 4) * 8;
+  const int trq = l15 >> 2, trp = (l15 & 3) * 4;       // this lane's row / column quad inside a transposing 4x16 block
+
+  zt_f32x4 acc[PPW][NT];
+#pragma unroll
+  for (int p = 0; p < PPW; ++p)
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[p][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const int oy0 = ty * HTH, ox0 = tx * HTW;
+    __syncthreads();
+    for (int e = tid; e < IR * IC * CT * 2; e += 256) {
+      int c8 = e % (CT * 2), p = e / (CT * 2);
+      int iy = p / IC, ixx = p - iy * IC;
+      int gy = oy0 - padH + iy, gx = ox0 - padW + ixx;
+      int c = c8 * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Cin) {
+        v = *reinterpret_cast<const uint4*>(a.x + ((size_t)gy * a.W + gx) * a.ldx + c);
+        if (c + 8 > a.Cin) {
+          zt_bf16 tmp[8];
+          __builtin_memcpy(tmp, &v, 16);
+          for (int j = 0; j < 8; ++j)
+            if (c + j >= a.Cin) tmp[j] = 0;
+          __builtin_memcpy(&v, tmp, 16);
+        }
+      }
+      *reinterpret_cast<uint4*>(xs + p * CIP + c) = v;
+    }
+    for (int e = tid; e < HTH * HTW * NT * 2; e += 256) {
+      int c8 = e % (NT * 2), p = e / (NT * 2);
+      int iy = p / HTW, ixx = p - iy * HTW;
+      int gy = oy0 + iy, gx = ox0 + ixx;
+      int c = c8 * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (gy < a.H && gx < a.W && c < a.Cout) {
+        v = *reinterpret_cast<const uint4*>(a.dz + ((size_t)gy * a.W + gx) * a.lddz + c);
+        if (c + 8 > a.Cout) {
+          zt_bf16 tmp[8];
+          __builtin_memcpy(tmp, &v, 16);
+          for (int j = 0; j < 8; ++j)
+            if (c + j >= a.Cout) tmp[j] = 0;
+          __builtin_memcpy(&v, tmp, 16);
+        }
+      }
+      *reinterpret_cast<uint4*>(zs + p * COP + c) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < HTH; ++r) {
+      zt_s16x8 bv[NT];
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        zt_s16x4 lo = zt_lds_read_tr16(zs + (r * HTW + g8 + trq) * COP + q * 16 + trp);
+        zt_s16x4 hi = zt_lds_read_tr16(zs + (r * HTW + g8 + 4 + trq) * COP + q * 16 + trp);
+        bv[q] = (zt_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int pi = 0; pi < PPW; ++pi) {
+        const int pr = wave + 4 * pi;
+        if (pr < NPAIR) {                    // wave-uniform
+          const int tap = pr / CT, cit = pr - tap * CT;
+          const int ky = tap / KW, kx = tap - ky * KW;
+          const zt_bf16* base = xs + ((r + ky) * IC + kx + g8 + trq) * CIP + cit * 16 + trp;
+          zt_s16x4 lo = zt_lds_read_tr16(base);
+          zt_s16x4 hi = zt_lds_read_tr16(base + 4 * CIP);
+          zt_s16x8 av = (zt_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int q = 0; q < NT; ++q) acc[pi][q] = zt_mfma_bf16(av, bv[q], acc[pi][q]);
+        }
+      }
+    }
+  }
+  float* out = a.slab + (size_t)blockIdx.x * (KH * KW * CT * 16 * NT * 16);
+  const int l4 = lane >> 4;
+#pragma unroll
+  for (int pi = 0; pi < PPW; ++pi) {
+    const int pr = wave + 4 * pi;
+    if (pr < NPAIR) {
+      const int tap = pr / CT, cit = pr - tap * CT;
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          out[((size_t)tap * CT * 16 + cit * 16 + l4 * 4 + j) * (NT * 16) + q * 16 + l15] = acc[pi][q][j];
+    }
+  }
+}
+
+template <int KH, int KW>
+int launch_wgrad_h(const WgradArgsH& a, int CT, int NT, int nblk, hipStream_t stream) {
+  dim3 grid(nblk), block(256);
+#define ZT_WG(ct, nt) hipLaunchKernelGGL((wgrad_mfma_bf16_kernel<KH, KW, ct, nt>), grid, block, 0, stream, a); return 0
+  if (CT == 1 && NT == 3) { ZT_WG(1, 3); }
+  if (CT == 1 && NT == 4) { ZT_WG(1, 4); }
+  if (CT == 3 && NT == 3) { ZT_WG(3, 3); }
+  if (CT == 3 && NT == 1) { ZT_WG(3, 1); }
+  if (CT == 4 && NT == 4) { ZT_WG(4, 4); }
+  if (CT == 4 && NT == 1) { ZT_WG(4, 1); }
+#undef ZT_WG
+  return ZT_EINVAL;
+}
+
+// torch fp32 [Cout][Cin][KH][KW] -> bf16 [tap][CoutP][ldk] (input channel fastest); transpose_flip: the data-gradient operator
+__global__ void __launch_bounds__(256) repack_w_bf16_kernel(const float* __restrict__ src, zt_bf16* __restrict__ dst, int Cout,
+                                                            int Cin, int KH, int KW, int CoutP, int ldk, int transpose_flip,
+                                                            int total) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int kx = idx % KW;
+  int ky = (idx / KW) % KH;
+  int ci = (idx / (KW * KH)) % Cin;
+  int co = idx / (KW * KH * Cin);
+  zt_bf16 v = zt_f2bf(src[idx]);
+  if (!transpose_flip) dst[((size_t)(ky * KW + kx) * CoutP + co) * ldk + ci] = v;
+  else dst[((size_t)((KH - 1 - ky) * KW + (KW - 1 - kx)) * CoutP + ci) * ldk + co] = v;
+}
+
 // torch [Cout][Cin][KH][KW] -> device [tap][Cin'][ldw] (forward) or the data-gradient form
 // [tap'][Cout][ldw] with taps flipped and in/out channels exchanged.
 __global__ void __launch_bounds__(256) repack_w_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout,
@@ -405,7 +687,7 @@ extern "C" int zt_conv2d_wgrad_nhwc_f32(const float* x, int ldx, const float* dz
   a.tilesX = zt_cdiv(W, WTW);
   a.ntiles = a.tilesX * zt_cdiv(H, WTH);
   size_t per = (size_t)KH * KW * CT * 16 * NT * 16 * sizeof(float);
-  int nblk = a.ntiles < 256 ? a.ntiles : 256;     // one resident workgroup per CU walks the pixel tiles
+  int nblk = a.ntiles < 512 ? a.ntiles : 512;
   if ((size_t)nblk * per > slab_bytes) nblk = (int)(slab_bytes / per);
   ZT_REQUIRE(nblk >= 1);
   int rc = ZT_EINVAL;
@@ -425,6 +707,70 @@ extern "C" int zt_repack_conv_weight_f32(const float* src, float* dst, int Cout,
   int total = Cout * Cin * KH * KW;
   hipLaunchKernelGGL(repack_w_kernel, dim3(zt_cdiv(total, 256)), dim3(256), 0, stream, src, dst, Cout, Cin, KH, KW, ldw,
                      co_off, transpose_flip, total);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_conv2d_nhwc_bf16(const void* x, int ldx, int N, int H, int W, int Cin, const void* w, int CoutP, int ldk,
+                                   const float* bias, void* y, int ldy, int out_f32_planar, int Cout, int KH, int KW, int stride,
+                                   int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi,
+                                   hipStream_t stream) {
+  ZT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  ZT_REQUIRE(ldx % 8 == 0 && ldk % 8 == 0 && CoutP % 16 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
+  ZT_REQUIRE(epi == 0 || aux);
+  ConvArgsH a;
+  a.x = (const zt_bf16*)x; a.w = (const zt_bf16*)w; a.bias = bias; a.aux = (const zt_bf16*)aux; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx;
+  a.Ho = (H + 2 * padH - KH) / stride + 1;
+  a.Wo = (W + 2 * padW - KW) / stride + 1;
+  a.Cout = Cout; a.CoutP = CoutP; a.ldk = ldk; a.ldy = ldy; a.ldaux = ldaux;
+  a.padH = padH; a.padW = padW; a.act = act; a.epi = epi; a.out_f32_planar = out_f32_planar; a.alpha = alpha;
+  a.tilesX = zt_cdiv(a.Wo, TW);
+  a.tilesY = zt_cdiv(a.Ho, TH);
+  ZT_REQUIRE(a.Ho > 0 && a.Wo > 0);
+  int c16 = (Cout + 15) / 16;
+  int NT = c16 >= 4 ? ((c16 % 4 == 0) ? 4 : (c16 % 3 == 0 ? 3 : 4)) : c16;
+  dim3 gb((unsigned)(a.tilesX * a.tilesY * N));
+  int rc = ZT_EINVAL;
+  if (KH == 3 && KW == 3 && stride == 1) rc = launch_conv_h<3, 3, 1>(a, NT, gb, stream);
+  else if (KH == 1 && KW == 1 && stride == 1) rc = launch_conv_h<1, 1, 1>(a, NT, gb, stream);
+  if (rc) return rc;
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout,
+                                         int KH, int KW, float* slab, size_t slab_bytes, float* grad_w, int accumulate,
+                                         hipStream_t stream) {
+  ZT_REQUIRE(x && dz && slab && grad_w && ldx % 8 == 0 && lddz % 8 == 0);
+  ZT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dz & 15) == 0);
+  int CT = (Cin + 15) / 16, NT = (Cout + 15) / 16;
+  WgradArgsH a;
+  a.x = (const zt_bf16*)x; a.dz = (const zt_bf16*)dz; a.slab = slab; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.Cout = Cout;
+  a.lddz = lddz;
+  a.tilesX = zt_cdiv(W, HTW);
+  a.ntiles = a.tilesX * zt_cdiv(H, HTH);
+  size_t per = (size_t)KH * KW * CT * 16 * NT * 16 * sizeof(float);
+  int nblk = a.ntiles < 512 ? a.ntiles : 512;
+  if ((size_t)nblk * per > slab_bytes) nblk = (int)(slab_bytes / per);
+  ZT_REQUIRE(nblk >= 1);
+  int rc = ZT_EINVAL;
+  if (KH == 3 && KW == 3) rc = launch_wgrad_h<3, 3>(a, CT, NT, nblk, stream);
+  else if (KH == 1 && KW == 1) rc = launch_wgrad_h<1, 1>(a, CT, NT, nblk, stream);
+  if (rc) return rc;
+  int total = KH * KW * CT * 16 * NT * 16;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(zt_cdiv(total, 64)), dim3(256), 0, stream, (const float*)slab, nblk, KH * KW,
+                     CT * 16, NT * 16, grad_w, Cout, Cin, accumulate);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_repack_conv_weight_bf16(const float* src, void* dst, int Cout, int Cin, int KH, int KW, int CoutP, int ldk,
+                                          int transpose_flip, hipStream_t stream) {
+  ZT_REQUIRE(src && dst && CoutP % 16 == 0 && ldk % 8 == 0);
+  int total = Cout * Cin * KH * KW;
+  hipLaunchKernelGGL(repack_w_bf16_kernel, dim3(zt_cdiv(total, 256)), dim3(256), 0, stream, src, (zt_bf16*)dst, Cout, Cin, KH, KW,
+                     CoutP, ldk, transpose_flip, total);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

@@ -36,14 +36,15 @@ struct PackSrc {
 };
 
 // dst[pix][0..ld): planar sources concatenated channel-wise, remaining channels zero
-__global__ void __launch_bounds__(256) pack_nhwc_kernel(float* __restrict__ dst, int ld, long long HW, PackSrc s) {
+template <typename T>
+__global__ void __launch_bounds__(256) pack_nhwc_kernel(T* __restrict__ dst, int ld, long long HW, PackSrc s) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= HW) return;
-  float* d = dst + i * ld;
+  T* d = dst + i * ld;
   int k = 0;
   for (int j = 0; j < 4; ++j)
-    for (int c = 0; c < s.c[j]; ++c) d[k++] = s.p[j][(size_t)c * HW + i];
-  for (; k < ld; ++k) d[k] = 0.f;
+    for (int c = 0; c < s.c[j]; ++c) ZtIO<T>::st(d + k++, s.p[j][(size_t)c * HW + i]);
+  for (; k < ld; ++k) ZtIO<T>::st(d + k, 0.f);
 }
 
 // model.py:149-152 (+ loss.py:54): L2 = clamp(x - n); L_pred1/2 = L11/12 - n11/12; (den1, den2) = pd(L2)
@@ -111,31 +112,33 @@ __global__ void __launch_bounds__(256) clamp_sub6_kernel(const float* __restrict
 }
 
 // backward of the above into the NHWC (ld) gradient of the residual r: dr[c] = -[1e-4 <= skip_c - r_c <= 1] * g_c
+template <typename T>
 __global__ void __launch_bounds__(256) clamp_sub6_bwd_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                              const float* __restrict__ r, const float* __restrict__ gA,
-                                                             const float* __restrict__ gB, float* __restrict__ dr, int ld,
+                                                             const float* __restrict__ gB, T* __restrict__ dr, int ld,
                                                              long long HW) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= HW) return;
-  float* d = dr + i * ld;
+  T* d = dr + i * ld;
   for (int c = 0; c < 3; ++c) {
     float pa = A[c * HW + i] - r[c * HW + i], pb = B[c * HW + i] - r[(c + 3) * HW + i];
-    d[c] = in_clamp(pa, ZT_EPS, 1.f) ? -gA[c * HW + i] : 0.f;
-    d[c + 3] = in_clamp(pb, ZT_EPS, 1.f) ? -gB[c * HW + i] : 0.f;
+    ZtIO<T>::st(d + c, in_clamp(pa, ZT_EPS, 1.f) ? -gA[c * HW + i] : 0.f);
+    ZtIO<T>::st(d + c + 3, in_clamp(pb, ZT_EPS, 1.f) ? -gB[c * HW + i] : 0.f);
   }
-  for (int k = 6; k < ld; ++k) d[k] = 0.f;
+  for (int k = 6; k < ld; ++k) ZtIO<T>::st(d + k, 0.f);
 }
 
 // Backward through H2 = clamp(x/s2), H11/H12 = clamp(L1x/s2x), (s21,s22) = pd(s2) and the Enhancer's
 // clamp(sigmoid) (model.py:79, 169-177): collects every gradient that reaches s2 and emits the Enhancer's
 // output-layer gradient  dO = ds2 * s2 (1 - s2) [s2 > 1e-4]  as NHWC (ld).
 // dIn5: planar [12][H][W] gradient of the full-res Denoise_2 input (ch 6-8 = dH2, 9-11 = ds2); dIn3/dIn4: half-res twins.
+template <typename T>
 __global__ void __launch_bounds__(256) post_enh_bwd_kernel(const float* __restrict__ x, const float* __restrict__ s2,
                                                            const float* __restrict__ L11, const float* __restrict__ L12,
                                                            const float* __restrict__ s21, const float* __restrict__ s22,
                                                            const float* __restrict__ dIn5, const float* __restrict__ dH2x,
                                                            const float* __restrict__ dIn3, const float* __restrict__ dIn4,
-                                                           const float* __restrict__ ds2_direct, float* __restrict__ dO,
+                                                           const float* __restrict__ ds2_direct, T* __restrict__ dO,
                                                            int ld, float* __restrict__ ds2_total, int H, int W) {
   const int h = H >> 1, w = W >> 1;
   int hx = blockIdx.x * 64 + threadIdx.x, hy = blockIdx.y * 4 + threadIdx.y;
@@ -160,24 +163,25 @@ __global__ void __launch_bounds__(256) post_enh_bwd_kernel(const float* __restri
       float gH2 = dIn5[(6 + c) * HW + pp] + dH2x[oo];
       float g = ds2_direct[oo] + dIn5[(9 + c) * HW + pp] + pdadj[k] + (in_clamp(q, ZT_EPS, 1.f) ? gH2 * (-q / s) : 0.f);
       if (ds2_total) ds2_total[oo] = g;
-      dO[pp * ld + c] = (s > ZT_EPS) ? g * s * (1.f - s) : 0.f;
+      ZtIO<T>::st(dO + pp * ld + c, (s > ZT_EPS) ? g * s * (1.f - s) : 0.f);
     }
   }
   if (ld > 3) {
     size_t p = (size_t)(2 * hy) * W + 2 * hx;
     const size_t offs[4] = {0, 1, (size_t)W, (size_t)W + 1};
     for (int k = 0; k < 4; ++k)
-      for (int j = 3; j < ld; ++j) dO[(p + offs[k]) * ld + j] = 0.f;
+      for (int j = 3; j < ld; ++j) ZtIO<T>::st(dO + (p + offs[k]) * ld + j, 0.f);
   }
 }
 
 // Gradients entering the three Denoise_1 invocations (model.py:149-152): dn11 = -dLp1, dn12 = -dLp2 (half res),
 // dn = -[1e-4 <= x - n <= 1] * pd^T(dden1, dden2) (full res); all NHWC (ld).
+template <typename T>
 __global__ void __launch_bounds__(256) d1_bwd_prep_kernel(const float* __restrict__ x, const float* __restrict__ n,
                                                           const float* __restrict__ dLp1, const float* __restrict__ dLp2,
                                                           const float* __restrict__ dden1, const float* __restrict__ dden2,
-                                                          float* __restrict__ dn, float* __restrict__ dn11,
-                                                          float* __restrict__ dn12, int ld, int H, int W) {
+                                                          T* __restrict__ dn, T* __restrict__ dn11,
+                                                          T* __restrict__ dn12, int ld, int H, int W) {
   const int h = H >> 1, w = W >> 1;
   int hx = blockIdx.x * 64 + threadIdx.x, hy = blockIdx.y * 4 + threadIdx.y;
   if (hx >= w || hy >= h) return;
@@ -192,15 +196,15 @@ __global__ void __launch_bounds__(256) d1_bwd_prep_kernel(const float* __restric
     for (int k = 0; k < 4; ++k) {
       size_t oo = c * HW + p + offs[k];
       float pre = x[oo] - n[oo];
-      dn[(p + offs[k]) * ld + c] = in_clamp(pre, ZT_EPS, 1.f) ? -adj[k] : 0.f;
+      ZtIO<T>::st(dn + (p + offs[k]) * ld + c, in_clamp(pre, ZT_EPS, 1.f) ? -adj[k] : 0.f);
     }
-    dn11[hp * ld + c] = -dLp1[c * hw + hp];
-    dn12[hp * ld + c] = -dLp2[c * hw + hp];
+    ZtIO<T>::st(dn11 + hp * ld + c, -dLp1[c * hw + hp]);
+    ZtIO<T>::st(dn12 + hp * ld + c, -dLp2[c * hw + hp]);
   }
   for (int j = 3; j < ld; ++j) {
-    for (int k = 0; k < 4; ++k) dn[(p + offs[k]) * ld + j] = 0.f;
-    dn11[hp * ld + j] = 0.f;
-    dn12[hp * ld + j] = 0.f;
+    for (int k = 0; k < 4; ++k) ZtIO<T>::st(dn + (p + offs[k]) * ld + j, 0.f);
+    ZtIO<T>::st(dn11 + hp * ld + j, 0.f);
+    ZtIO<T>::st(dn12 + hp * ld + j, 0.f);
   }
 }
 
@@ -215,17 +219,18 @@ __global__ void __launch_bounds__(256) add3_kernel(const float* __restrict__ a, 
 }
 
 // out = g * [a > 0]  (ReLU backward) on NHWC buffers
-__global__ void __launch_bounds__(256) relu_mask_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ a,
-                                                        int lda, float* __restrict__ out, int ldo, int C, long long total4) {
+template <typename T>
+__global__ void __launch_bounds__(256) relu_mask_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ a,
+                                                        int lda, T* __restrict__ out, int ldo, int C, long long total4) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
   const int Q = C >> 2;
   int q = (int)(i % Q);
   long long p = i / Q;
-  float4 gv = *reinterpret_cast<const float4*>(g + p * ldg + q * 4);
-  float4 av = *reinterpret_cast<const float4*>(a + p * lda + q * 4);
+  float4 gv = ZtIO<T>::ld4(g + p * ldg + q * 4);
+  float4 av = ZtIO<T>::ld4(a + p * lda + q * 4);
   gv.x = av.x > 0.f ? gv.x : 0.f; gv.y = av.y > 0.f ? gv.y : 0.f; gv.z = av.z > 0.f ? gv.z : 0.f; gv.w = av.w > 0.f ? gv.w : 0.f;
-  *reinterpret_cast<float4*>(out + p * ldo + q * 4) = gv;
+  ZtIO<T>::st4(out + p * ldo + q * 4, gv);
 }
 
 // mode 0: a + p0   1: clamp(a - b, p0, p1)   2: clamp(a / b, p0, p1)
@@ -259,14 +264,15 @@ extern "C" int zt_prep_input_f32(const float* inp, float* x, float* L11, float* 
   return ZT_OK;
 }
 
-extern "C" int zt_pack_nhwc_f32(float* dst, int ld, long long HW, const float* s0, int c0, const float* s1, int c1,
+extern "C" int zt_pack_nhwc(void* dst, int dt, int ld, long long HW, const float* s0, int c0, const float* s1, int c1,
                                 const float* s2, int c2, const float* s3, int c3, hipStream_t stream) {
   ZT_REQUIRE(dst && c0 + c1 + c2 + c3 <= ld && c0 >= 0 && c1 >= 0 && c2 >= 0 && c3 >= 0);
   ZT_REQUIRE((c0 == 0 || s0) && (c1 == 0 || s1) && (c2 == 0 || s2) && (c3 == 0 || s3));
   PackSrc s;
   s.p[0] = s0; s.p[1] = s1; s.p[2] = s2; s.p[3] = s3;
   s.c[0] = c0; s.c[1] = c1; s.c[2] = c2; s.c[3] = c3;
-  hipLaunchKernelGGL(pack_nhwc_kernel, dim3((unsigned)zt_cdivl(HW, 256)), dim3(256), 0, stream, dst, ld, HW, s);
+  if (dt == 0) hipLaunchKernelGGL(pack_nhwc_kernel<float>, dim3((unsigned)zt_cdivl(HW, 256)), dim3(256), 0, stream, (float*)dst, ld, HW, s);
+  else hipLaunchKernelGGL(pack_nhwc_kernel<zt_bf16>, dim3((unsigned)zt_cdivl(HW, 256)), dim3(256), 0, stream, (zt_bf16*)dst, ld, HW, s);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
@@ -299,32 +305,41 @@ extern "C" int zt_clamp_sub6_f32(const float* A, const float* B, const float* r,
   return ZT_OK;
 }
 
-extern "C" int zt_clamp_sub6_bwd_f32(const float* A, const float* B, const float* r, const float* gA, const float* gB,
-                                     float* dr, int ld, long long HW, hipStream_t stream) {
+extern "C" int zt_clamp_sub6_bwd(const float* A, const float* B, const float* r, const float* gA, const float* gB,
+                                 void* dr, int dt, int ld, long long HW, hipStream_t stream) {
   ZT_REQUIRE(A && B && r && gA && gB && dr && ld >= 6);
-  hipLaunchKernelGGL(clamp_sub6_bwd_kernel, dim3((unsigned)zt_cdivl(HW, 256)), dim3(256), 0, stream, A, B, r, gA, gB, dr, ld, HW);
+  if (dt == 0) hipLaunchKernelGGL(clamp_sub6_bwd_kernel<float>, dim3((unsigned)zt_cdivl(HW, 256)), dim3(256), 0, stream, A, B, r, gA, gB, (float*)dr, ld, HW);
+  else hipLaunchKernelGGL(clamp_sub6_bwd_kernel<zt_bf16>, dim3((unsigned)zt_cdivl(HW, 256)), dim3(256), 0, stream, A, B, r, gA, gB, (zt_bf16*)dr, ld, HW);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
 
-extern "C" int zt_post_enh_bwd_f32(const float* x, const float* s2, const float* L11, const float* L12, const float* s21,
-                                   const float* s22, const float* dIn5, const float* dH2x, const float* dIn3,
-                                   const float* dIn4, const float* ds2_direct, float* dO, int ld, float* ds2_total, int H,
-                                   int W, hipStream_t stream) {
+extern "C" int zt_post_enh_bwd(const float* x, const float* s2, const float* L11, const float* L12, const float* s21,
+                               const float* s22, const float* dIn5, const float* dH2x, const float* dIn3,
+                               const float* dIn4, const float* ds2_direct, void* dO, int dt, int ld, float* ds2_total, int H,
+                               int W, hipStream_t stream) {
   ZT_REQUIRE(x && s2 && L11 && L12 && s21 && s22 && dIn5 && dH2x && dIn3 && dIn4 && ds2_direct && dO && ld >= 3);
   ZT_REQUIRE(H % 2 == 0 && W % 2 == 0);
-  hipLaunchKernelGGL(post_enh_bwd_kernel, grid_half(H, W), dim3(64, 4), 0, stream, x, s2, L11, L12, s21, s22, dIn5, dH2x,
-                     dIn3, dIn4, ds2_direct, dO, ld, ds2_total, H, W);
+  if (dt == 0)
+    hipLaunchKernelGGL(post_enh_bwd_kernel<float>, grid_half(H, W), dim3(64, 4), 0, stream, x, s2, L11, L12, s21, s22, dIn5, dH2x,
+                       dIn3, dIn4, ds2_direct, (float*)dO, ld, ds2_total, H, W);
+  else
+    hipLaunchKernelGGL(post_enh_bwd_kernel<zt_bf16>, grid_half(H, W), dim3(64, 4), 0, stream, x, s2, L11, L12, s21, s22, dIn5, dH2x,
+                       dIn3, dIn4, ds2_direct, (zt_bf16*)dO, ld, ds2_total, H, W);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
 
-extern "C" int zt_d1_bwd_prep_f32(const float* x, const float* n, const float* dLp1, const float* dLp2, const float* dden1,
-                                  const float* dden2, float* dn, float* dn11, float* dn12, int ld, int H, int W,
-                                  hipStream_t stream) {
+extern "C" int zt_d1_bwd_prep(const float* x, const float* n, const float* dLp1, const float* dLp2, const float* dden1,
+                              const float* dden2, void* dn, void* dn11, void* dn12, int dt, int ld, int H, int W,
+                              hipStream_t stream) {
   ZT_REQUIRE(x && n && dLp1 && dLp2 && dden1 && dden2 && dn && dn11 && dn12 && ld >= 3 && H % 2 == 0 && W % 2 == 0);
-  hipLaunchKernelGGL(d1_bwd_prep_kernel, grid_half(H, W), dim3(64, 4), 0, stream, x, n, dLp1, dLp2, dden1, dden2, dn, dn11,
-                     dn12, ld, H, W);
+  if (dt == 0)
+    hipLaunchKernelGGL(d1_bwd_prep_kernel<float>, grid_half(H, W), dim3(64, 4), 0, stream, x, n, dLp1, dLp2, dden1, dden2, (float*)dn,
+                       (float*)dn11, (float*)dn12, ld, H, W);
+  else
+    hipLaunchKernelGGL(d1_bwd_prep_kernel<zt_bf16>, grid_half(H, W), dim3(64, 4), 0, stream, x, n, dLp1, dLp2, dden1, dden2,
+                       (zt_bf16*)dn, (zt_bf16*)dn11, (zt_bf16*)dn12, ld, H, W);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
@@ -336,11 +351,16 @@ extern "C" int zt_add3_f32(const float* a, const float* b, const float* c, float
   return ZT_OK;
 }
 
-extern "C" int zt_relu_mask_nhwc_f32(const float* g, int ldg, const float* a, int lda, float* out, int ldo, long long npix, int C,
-                                     hipStream_t stream) {
+extern "C" int zt_relu_mask_nhwc(const void* g, int dt, int ldg, const void* a, int lda, void* out, int ldo, long long npix, int C,
+                                 hipStream_t stream) {
   ZT_REQUIRE(g && a && out && C % 4 == 0 && ldg % 4 == 0 && lda % 4 == 0 && ldo % 4 == 0);
   long long total4 = npix * (C / 4);
-  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, g, ldg, a, lda, out, ldo, C, total4);
+  if (dt == 0)
+    hipLaunchKernelGGL(relu_mask_kernel<float>, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, (const float*)g, ldg,
+                       (const float*)a, lda, (float*)out, ldo, C, total4);
+  else
+    hipLaunchKernelGGL(relu_mask_kernel<zt_bf16>, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, (const zt_bf16*)g, ldg,
+                       (const zt_bf16*)a, lda, (zt_bf16*)out, ldo, C, total4);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

@@ -8,7 +8,8 @@
 namespace {
 
 // partial[((n*nblk + blk)*2 + {0:sum,1:sumsq})*C + c]
-__global__ void __launch_bounds__(256) chan_stats_kernel(const float* __restrict__ x, int ldx, int HW, int C, int nblk,
+template <typename T>
+__global__ void __launch_bounds__(256) chan_stats_kernel(const T* __restrict__ x, int ldx, int HW, int C, int nblk,
                                                          float* __restrict__ partial) {
   __shared__ float4 sh_s[256];
   __shared__ float4 sh_q[256];
@@ -20,9 +21,9 @@ __global__ void __launch_bounds__(256) chan_stats_kernel(const float* __restrict
   const int p0 = blk * chunk, p1 = min(HW, p0 + chunk);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = s;
   if (row < R) {
-    const float* base = x + (size_t)n * HW * ldx + q * 4;
+    const T* base = x + (size_t)n * HW * ldx + q * 4;
     for (int p = p0 + row; p < p1; p += R) {
-      float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * ldx);
+      float4 v = ZtIO<T>::ld4(base + (size_t)p * ldx);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
     }
@@ -105,9 +106,10 @@ __global__ void __launch_bounds__(256) norm_finalize_kernel(const float* __restr
 }
 
 // y = [outer_relu]( [res +] [inner_relu](x*scale + shift) )
-__global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict__ x, int ldx,
+template <typename T>
+__global__ void __launch_bounds__(256) norm_apply_kernel(const T* __restrict__ x, int ldx,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         const float* __restrict__ res, int ldres, float* __restrict__ y,
+                                                         const T* __restrict__ res, int ldres, T* __restrict__ y,
                                                          int ldy, int HW, int C, int inner_relu, int outer_relu,
                                                          long long total4) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -116,22 +118,23 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const float* __restrict
   int q = (int)(i % Q);
   long long p = i / Q;            // global pixel index over N*HW
   int n = (int)(p / HW);
-  float4 v = *reinterpret_cast<const float4*>(x + p * ldx + q * 4);
+  float4 v = ZtIO<T>::ld4(x + p * ldx + q * 4);
   float4 sc = *reinterpret_cast<const float4*>(scale + n * C + q * 4);
   float4 sf = *reinterpret_cast<const float4*>(shift + n * C + q * 4);
   v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
   if (inner_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
   if (res) {
-    float4 r = *reinterpret_cast<const float4*>(res + p * ldres + q * 4);
+    float4 r = ZtIO<T>::ld4(res + p * ldres + q * 4);
     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
   }
   if (outer_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-  *reinterpret_cast<float4*>(y + p * ldy + q * 4) = v;
+  ZtIO<T>::st4(y + p * ldy + q * 4, v);
 }
 
 // BN(+ReLU) backward, stage 1: partial[(blk*2 + {0: sum dyh, 1: sum dyh*zhat})*C + c], dyh = dy * [x*scale+shift > 0]
-__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ dy, int lddy,
-                                                            const float* __restrict__ z, int ldz,
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy,
+                                                            const T* __restrict__ z, int ldz,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             int HW, int C, int nblk, float* __restrict__ partial) {
@@ -148,8 +151,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
     float4 sc = *reinterpret_cast<const float4*>(scale + q * 4), sf = *reinterpret_cast<const float4*>(shift + q * 4);
     float4 mu = *reinterpret_cast<const float4*>(mean + q * 4), rs = *reinterpret_cast<const float4*>(rstd + q * 4);
     for (int p = p0 + row; p < p1; p += R) {
-      float4 g = *reinterpret_cast<const float4*>(dy + (size_t)p * lddy + q * 4);
-      float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * ldz + q * 4);
+      float4 g = ZtIO<T>::ld4(dy + (size_t)p * lddy + q * 4);
+      float4 v = ZtIO<T>::ld4(z + (size_t)p * ldz + q * 4);
       float gx = (v.x * sc.x + sf.x > 0.f) ? g.x : 0.f, gy = (v.y * sc.y + sf.y > 0.f) ? g.y : 0.f;
       float gz = (v.z * sc.z + sf.z > 0.f) ? g.z : 0.f, gw = (v.w * sc.w + sf.w > 0.f) ? g.w : 0.f;
       sa.x += gx; sa.y += gy; sa.z += gz; sa.w += gw;
@@ -195,19 +198,20 @@ __global__ void __launch_bounds__(256) partial_reduce_kernel(const float* __rest
 }
 
 // dz = gamma*rstd * (dyh - sum_dyh/n - zhat * sum_dyh_zhat/n)
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ z,
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z,
                                                            int ldz, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ sums,
-                                                           float inv_n, float* __restrict__ dz, int lddz, int C,
+                                                           float inv_n, T* __restrict__ dz, int lddz, int C,
                                                            long long total4) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
   const int Q = C >> 2;
   int q = (int)(i % Q);
   long long p = i / Q;
-  float4 g = *reinterpret_cast<const float4*>(dy + p * lddy + q * 4);
-  float4 v = *reinterpret_cast<const float4*>(z + p * ldz + q * 4);
+  float4 g = ZtIO<T>::ld4(dy + p * lddy + q * 4);
+  float4 v = ZtIO<T>::ld4(z + p * ldz + q * 4);
   float4 sc = *reinterpret_cast<const float4*>(scale + q * 4), sf = *reinterpret_cast<const float4*>(shift + q * 4);
   float4 mu = *reinterpret_cast<const float4*>(mean + q * 4), rs = *reinterpret_cast<const float4*>(rstd + q * 4);
   float4 s1 = *reinterpret_cast<const float4*>(sums + q * 4), s2 = *reinterpret_cast<const float4*>(sums + C + q * 4);
@@ -220,15 +224,16 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
   }
   ZT_BN1(x) ZT_BN1(y) ZT_BN1(z) ZT_BN1(w)
 #undef ZT_BN1
-  *reinterpret_cast<float4*>(dz + p * lddz + q * 4) = o;
+  ZtIO<T>::st4(dz + p * lddz + q * 4, o);
 }
 
 }  // namespace
 
-extern "C" int zt_chan_stats_nhwc_f32(const float* x, int ldx, int N, int HW, int C, int nblk, float* partial,
-                                      hipStream_t stream) {
-  ZT_REQUIRE(x && partial && C % 4 == 0 && C >= 4 && C <= 1024 && ldx % 4 == 0 && nblk > 0 && ((uintptr_t)x & 15) == 0);
-  hipLaunchKernelGGL(chan_stats_kernel, dim3(nblk, N), dim3(256), 0, stream, x, ldx, HW, C, nblk, partial);
+extern "C" int zt_chan_stats_nhwc(const void* x, int dt, int ldx, int N, int HW, int C, int nblk, float* partial,
+                                  hipStream_t stream) {
+  ZT_REQUIRE(x && partial && C % 4 == 0 && C >= 4 && C <= 1024 && ldx % 4 == 0 && nblk > 0 && ((uintptr_t)x & 7) == 0);
+  if (dt == 0) hipLaunchKernelGGL(chan_stats_kernel<float>, dim3(nblk, N), dim3(256), 0, stream, (const float*)x, ldx, HW, C, nblk, partial);
+  else hipLaunchKernelGGL(chan_stats_kernel<zt_bf16>, dim3(nblk, N), dim3(256), 0, stream, (const zt_bf16*)x, ldx, HW, C, nblk, partial);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
@@ -246,23 +251,31 @@ extern "C" int zt_norm_finalize_f32(const float* partial, int nblk, int N, int C
   return ZT_OK;
 }
 
-extern "C" int zt_norm_apply_nhwc_f32(const float* x, int ldx, const float* scale, const float* shift, const float* res,
-                                      int ldres, float* y, int ldy, int N, int HW, int C, int inner_relu, int outer_relu,
-                                      hipStream_t stream) {
+extern "C" int zt_norm_apply_nhwc(const void* x, int dt, int ldx, const float* scale, const float* shift, const void* res,
+                                  int ldres, void* y, int ldy, int N, int HW, int C, int inner_relu, int outer_relu,
+                                  hipStream_t stream) {
   ZT_REQUIRE(x && y && scale && shift && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!res || ldres % 4 == 0));
   long long total4 = (long long)N * HW * (C / 4);
-  hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, x, ldx, scale, shift,
-                     res, ldres, y, ldy, HW, C, inner_relu, outer_relu, total4);
+  if (dt == 0)
+    hipLaunchKernelGGL(norm_apply_kernel<float>, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, (const float*)x, ldx,
+                       scale, shift, (const float*)res, ldres, (float*)y, ldy, HW, C, inner_relu, outer_relu, total4);
+  else
+    hipLaunchKernelGGL(norm_apply_kernel<zt_bf16>, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, (const zt_bf16*)x,
+                       ldx, scale, shift, (const zt_bf16*)res, ldres, (zt_bf16*)y, ldy, HW, C, inner_relu, outer_relu, total4);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
 
-extern "C" int zt_bn_bwd_reduce_f32(const float* dy, int lddy, const float* z, int ldz, const float* scale,
-                                    const float* shift, const float* mean, const float* rstd, int HW, int C, int nblk,
-                                    float* partial, hipStream_t stream) {
+extern "C" int zt_bn_bwd_reduce(const void* dy, int dt, int lddy, const void* z, int ldz, const float* scale,
+                                const float* shift, const float* mean, const float* rstd, int HW, int C, int nblk,
+                                float* partial, hipStream_t stream) {
   ZT_REQUIRE(dy && z && partial && C % 4 == 0 && C <= 1024);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, stream, dy, lddy, z, ldz, scale, shift, mean, rstd, HW,
-                     C, nblk, partial);
+  if (dt == 0)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, stream, (const float*)dy, lddy, (const float*)z, ldz,
+                       scale, shift, mean, rstd, HW, C, nblk, partial);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<zt_bf16>, dim3(nblk), dim3(256), 0, stream, (const zt_bf16*)dy, lddy, (const zt_bf16*)z,
+                       ldz, scale, shift, mean, rstd, HW, C, nblk, partial);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
@@ -275,13 +288,17 @@ extern "C" int zt_partial_reduce_f32(const float* partial, int nblk, int stride,
   return ZT_OK;
 }
 
-extern "C" int zt_bn_bwd_apply_f32(const float* dy, int lddy, const float* z, int ldz, const float* scale,
-                                   const float* shift, const float* mean, const float* rstd, const float* sums,
-                                   float* dz, int lddz, int HW, int C, hipStream_t stream) {
+extern "C" int zt_bn_bwd_apply(const void* dy, int dt, int lddy, const void* z, int ldz, const float* scale,
+                               const float* shift, const float* mean, const float* rstd, const float* sums,
+                               void* dz, int lddz, int HW, int C, hipStream_t stream) {
   ZT_REQUIRE(dy && z && dz && sums && C % 4 == 0);
   long long total4 = (long long)HW * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, dy, lddy, z, ldz,
-                     scale, shift, mean, rstd, sums, 1.f / (float)HW, dz, lddz, C, total4);
+  if (dt == 0)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, (const float*)dy,
+                       lddy, (const float*)z, ldz, scale, shift, mean, rstd, sums, 1.f / (float)HW, (float*)dz, lddz, C, total4);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<zt_bf16>, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, (const zt_bf16*)dy,
+                       lddy, (const zt_bf16*)z, ldz, scale, shift, mean, rstd, sums, 1.f / (float)HW, (zt_bf16*)dz, lddz, C, total4);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

@@ -18,8 +18,15 @@ D2 = "denoise_2"
 
 
 class Engine:
-    def __init__(self, ops, params, buffers, is_WB=False, device=None):
-        """params: {name: tensor} of the 20 trainable tensors (torch layout, on device); buffers: BN running stats."""
+    def __init__(self, ops, params, buffers, is_WB=False, device=None, precision="fp32"):
+        """params: {name: tensor} of the 20 trainable tensors (torch layout, on device); buffers: BN running stats.
+        precision: "fp32" (parity mode: exact-fp32 MFMA, fp32 activations) or "bf16" (throughput mode: bf16 activations and
+        weights in HBM, fp32 accumulation / statistics / loss / optimizer)."""
+        assert precision in ("fp32", "bf16")
+        self.precision = precision
+        self.adt = torch.bfloat16 if precision == "bf16" else torch.float32      # NHWC activation storage type
+        self.dt = 1 if precision == "bf16" else 0
+        self.lda = 8 if precision == "bf16" else 4                              # channel-stride granule of thin NHWC buffers
         self.ops, self.lib = ops, ops.lib
         self.p, self.buf = params, buffers
         self.is_WB = is_WB
@@ -42,32 +49,47 @@ class Engine:
     def repack_weights(self):
         """torch-layout parameters -> device conv layouts (forward and data-gradient operators)."""
         o, p, wd = self.ops, self.p, self.wd
+        rp = o.repack_weight_bf16 if self.dt else o.repack_weight
         for pre in (D1 + ".conv1", D1 + ".conv2", D1 + ".conv3", D2 + ".conv1", D2 + ".conv2", D2 + ".conv3",
                     "enhance.in_conv.0", "enhance.conv.0", "enhance.out_conv.0"):
             w = p[pre + ".weight"]
-            wd[pre] = o.repack_weight(w, out=wd.get(pre))
+            wd[pre] = rp(w, out=wd.get(pre))
             if pre not in (D1 + ".conv1", "enhance.in_conv.0"):        # inputs of these need no gradient
-                wd[pre + "/T"] = o.repack_weight(w, transpose_flip=True, out=wd.get(pre + "/T"))
+                wd[pre + "/T"] = rp(w, transpose_flip=True, out=wd.get(pre + "/T"))
+
+    def _conv(self, x, wkey, bias, cout, k, act=None, out_planar=False, aux=None, epi=0):
+        """stride-1 'same' convolution of the enhancement nets in the engine's precision"""
+        pad = (k // 2, k // 2)
+        if self.dt:
+            return self.ops.conv2d_bf16(x, self.wd[wkey], bias, cout, k, k, pad, act, out_planar=out_planar, aux=aux, epi=epi)
+        return self.ops.conv2d(x, self.wd[wkey], bias, cout, k, k, 1, pad, act, out_planar=out_planar, aux=aux, epi=epi)
+
+    def _wgrad(self, x, dz, cout, k, gname):
+        fn = self.ops.conv2d_wgrad_bf16 if self.dt else self.ops.conv2d_wgrad
+        fn(x, dz, cout, k, k, self.g[gname], accumulate=True)
+
+    def _newa(self, *shape):
+        return torch.empty(shape, dtype=self.adt, device=self.dev)
 
     def _pack(self, ld, HW, srcs, H, W):
-        dst = self._new(1, H, W, ld)
+        dst = self._newa(1, H, W, ld)
         a = []
         for t in srcs:
             a += [t, t.shape[1]]
         while len(a) < 8:
             a += [None, 0]
-        self.lib.call("zt_pack_nhwc_f32", dst, ld, HW, *a, self._stream())
+        self.lib.call("zt_pack_nhwc", dst, self.dt, ld, HW, *a, self._stream())
         return dst
 
     # ------------------------------------------------------------------------------------------------ denoisers
     def _denoise_fwd(self, pre, srcs, H, W, cin, cout, key):
         """conv3x3+LReLU, conv3x3+LReLU, conv1x1 on cat(srcs) (model.py:15-44). Returns planar [1,cout,H,W]."""
-        o, p, wd = self.ops, self.p, self.wd
-        ld = (cin + 3) // 4 * 4
+        p = self.p
+        ld = (cin + self.lda - 1) // self.lda * self.lda
         u = self._pack(ld, H * W, srcs, H, W)
-        a1 = o.conv2d(CV(u, 0, cin), wd[pre + ".conv1"], p[pre + ".conv1.bias"], 48, 3, 3, 1, (1, 1), "lrelu")
-        a2 = o.conv2d(a1, wd[pre + ".conv2"], p[pre + ".conv2.bias"], 48, 3, 3, 1, (1, 1), "lrelu")
-        r = o.conv2d(a2, wd[pre + ".conv3"], p[pre + ".conv3.bias"], cout, 1, 1, 1, (0, 0), None, out_planar=True)
+        a1 = self._conv(CV(u, 0, cin), pre + ".conv1", p[pre + ".conv1.bias"], 48, 3, "lrelu")
+        a2 = self._conv(a1, pre + ".conv2", p[pre + ".conv2.bias"], 48, 3, "lrelu")
+        r = self._conv(a2, pre + ".conv3", p[pre + ".conv3.bias"], cout, 1, None, out_planar=True)
         if self.keep:
             self.sv[key] = (u, a1, a2, cin)
         return r
@@ -81,31 +103,29 @@ class Engine:
     def _denoise_bwd(self, pre, key, dr, cout, want_input_grad):
         """dr: NHWC gradient of the 1x1 output (first `cout` channels valid).  Accumulates parameter grads; returns the planar
         [1,cin,H,W] gradient of the packed input when requested."""
-        o, wd, g = self.ops, self.wd, self.g
         u, a1, a2, cin = self.sv[key]
-        H, W = a1.shape[1], a1.shape[2]
         drv = CV(dr, 0, cout)
-        o.conv2d_wgrad(a2, drv, cout, 1, 1, g[pre + ".conv3.weight"], accumulate=True)
+        self._wgrad(a2, drv, cout, 1, pre + ".conv3.weight")
         self._bias_grad(dr, cout, pre + ".conv3.bias")
-        dz2 = o.conv2d(drv, wd[pre + ".conv3/T"], None, 48, 1, 1, 1, (0, 0), None, aux=a2, epi=1)
-        o.conv2d_wgrad(a1, dz2, 48, 3, 3, g[pre + ".conv2.weight"], accumulate=True)
+        dz2 = self._conv(drv, pre + ".conv3/T", None, 48, 1, None, aux=a2, epi=1)
+        self._wgrad(a1, dz2, 48, 3, pre + ".conv2.weight")
         self._bias_grad(dz2, 48, pre + ".conv2.bias")
-        dz1 = o.conv2d(dz2, wd[pre + ".conv2/T"], None, 48, 3, 3, 1, (1, 1), None, aux=a1, epi=1)
-        o.conv2d_wgrad(CV(u, 0, cin), dz1, 48, 3, 3, g[pre + ".conv1.weight"], accumulate=True)
+        dz1 = self._conv(dz2, pre + ".conv2/T", None, 48, 3, None, aux=a1, epi=1)
+        self._wgrad(CV(u, 0, cin), dz1, 48, 3, pre + ".conv1.weight")
         self._bias_grad(dz1, 48, pre + ".conv1.bias")
         if want_input_grad:
-            return o.conv2d(dz1, wd[pre + ".conv1/T"], None, cin, 3, 3, 1, (1, 1), None, out_planar=True)
+            return self._conv(dz1, pre + ".conv1/T", None, cin, 3, None, out_planar=True)
         return None
 
     # ------------------------------------------------------------------------------------------------ enhancer
     def _enhancer_fwd(self, wpH, wps, L2, H, W):
         """model.py:47-81."""
         o, p, wd, b = self.ops, self.p, self.wd, self.buf
-        u = self._pack(12, H * W, [wpH, wps, L2], H, W)
-        f = o.conv2d(CV(u, 0, 9), wd["enhance.in_conv.0"], p["enhance.in_conv.0.bias"], 64, 3, 3, 1, (1, 1), "relu")
+        u = self._pack(16 if self.dt else 12, H * W, [wpH, wps, L2], H, W)
+        f = self._conv(CV(u, 0, 9), "enhance.in_conv.0", p["enhance.in_conv.0.bias"], 64, 3, "relu")
         feats, zs, stats = [f], [], []
         for _ in range(3):
-            z = o.conv2d(f, wd["enhance.conv.0"], p["enhance.conv.0.bias"], 64, 3, 3, 1, (1, 1), None)
+            z = self._conv(f, "enhance.conv.0", p["enhance.conv.0.bias"], 64, 3, None)
             if self.training:
                 part = o.chan_stats(z)
                 st = o.norm_finalize(part, 1, 64, H * W, 1, p["enhance.conv.1.weight"], p["enhance.conv.1.bias"],
@@ -118,7 +138,7 @@ class Engine:
             feats.append(f)
             zs.append(z)
             stats.append(st)
-        s2 = o.conv2d(f, wd["enhance.out_conv.0"], p["enhance.out_conv.0.bias"], 3, 3, 3, 1, (1, 1), "sigmoid_clamp", out_planar=True)
+        s2 = self._conv(f, "enhance.out_conv.0", p["enhance.out_conv.0.bias"], 3, 3, "sigmoid_clamp", out_planar=True)
         if self.keep:
             self.sv["E"] = (u, feats, zs, stats)
         return s2
@@ -129,21 +149,21 @@ class Engine:
         u, feats, zs, stats = self.sv["E"]
         H, W = feats[0].shape[1], feats[0].shape[2]
         dOv = CV(dO, 0, 3)
-        o.conv2d_wgrad(feats[3], dOv, 3, 3, 3, g["enhance.out_conv.0.weight"], accumulate=True)
+        self._wgrad(feats[3], dOv, 3, 3, "enhance.out_conv.0.weight")
         self._bias_grad(dO, 3, "enhance.out_conv.0.bias")
-        df = o.conv2d(dOv, wd["enhance.out_conv.0/T"], None, 64, 3, 3, 1, (1, 1), None)
+        df = self._conv(dOv, "enhance.out_conv.0/T", None, 64, 3, None)
         for i in (2, 1, 0):
             sc, sh, mu, rs = stats[i]
             if not self.training:
                 raise NotImplementedError("backward through eval-mode BatchNorm (reference train.py:138 quirk) is not built yet")
             dz = o.bn_relu_bwd(df, zs[i], sc, sh, mu, rs, g["enhance.conv.1.weight"], g["enhance.conv.1.bias"])
-            o.conv2d_wgrad(feats[i], dz, 64, 3, 3, g["enhance.conv.0.weight"], accumulate=True)
+            self._wgrad(feats[i], dz, 64, 3, "enhance.conv.0.weight")
             self._bias_grad(dz, 64, "enhance.conv.0.bias")
-            df = o.conv2d(dz, wd["enhance.conv.0/T"], None, 64, 3, 3, 1, (1, 1), None, aux=df, epi=3)
+            df = self._conv(dz, "enhance.conv.0/T", None, 64, 3, None, aux=df, epi=3)
         # through the in_conv ReLU: mask by the saved activation (epi 2 of a 1x1 identity is overkill -> dedicated op)
-        dz0 = self._new(1, H, W, 64)
-        self.lib.call("zt_relu_mask_nhwc_f32", df, 64, feats[0], 64, dz0, 64, H * W, 64, self._stream())
-        o.conv2d_wgrad(CV(u, 0, 9), dz0, 64, 3, 3, g["enhance.in_conv.0.weight"], accumulate=True)
+        dz0 = self._newa(1, H, W, 64)
+        self.lib.call("zt_relu_mask_nhwc", df, self.dt, 64, feats[0], 64, dz0, 64, H * W, 64, self._stream())
+        self._wgrad(CV(u, 0, 9), dz0, 64, 3, "enhance.in_conv.0.weight")
         self._bias_grad(dz0, 64, "enhance.in_conv.0.bias")
 
     # ------------------------------------------------------------------------------------------------ forward
@@ -294,21 +314,22 @@ class Engine:
         dH2x = o.localvar_bwd(DH2, gV, 1.0)
         o.localvar_bwd(DN, gV, 1.0, out=dH2x)
         # ---- through the three Denoise_2 invocations (model.py:179-192)
-        dr5, dr3, dr4 = self._new(1, H, W, 8), self._new(1, h, w, 8), self._new(1, h, w, 8)
-        lib.call("zt_clamp_sub6_bwd_f32", v["H2"], v["s2"], v["r5"], dH3, ds3, dr5, 8, HW, s)
-        lib.call("zt_clamp_sub6_bwd_f32", v["H11"], v["s21"], v["r3"], dH3p, dH3p[:, 3:], dr3, 8, hw, s)
-        lib.call("zt_clamp_sub6_bwd_f32", v["H12"], v["s22"], v["r4"], dH4p, dH4p[:, 3:], dr4, 8, hw, s)
+        dr5, dr3, dr4 = self._newa(1, H, W, 8), self._newa(1, h, w, 8), self._newa(1, h, w, 8)
+        lib.call("zt_clamp_sub6_bwd", v["H2"], v["s2"], v["r5"], dH3, ds3, dr5, self.dt, 8, HW, s)
+        lib.call("zt_clamp_sub6_bwd", v["H11"], v["s21"], v["r3"], dH3p, dH3p[:, 3:], dr3, self.dt, 8, hw, s)
+        lib.call("zt_clamp_sub6_bwd", v["H12"], v["s22"], v["r4"], dH4p, dH4p[:, 3:], dr4, self.dt, 8, hw, s)
         dIn3 = self._denoise_bwd(D2, "D2a", dr3, 6, True)
         dIn4 = self._denoise_bwd(D2, "D2b", dr4, 6, True)
         dIn5 = self._denoise_bwd(D2, "D2c", dr5, 6, True)
         # ---- everything that reaches s2 -> Enhancer
-        dO = self._new(1, H, W, 4)
-        lib.call("zt_post_enh_bwd_f32", v["x"], v["s2"], v["L11"], v["L12"], v["s21"], v["s22"], dIn5, dH2x, dIn3, dIn4, ds2,
-                 dO, 4, None, H, W, s)
+        dO = self._newa(1, H, W, self.lda)
+        lib.call("zt_post_enh_bwd", v["x"], v["s2"], v["L11"], v["L12"], v["s21"], v["s22"], dIn5, dH2x, dIn3, dIn4, ds2,
+                 dO, self.dt, self.lda, None, H, W, s)
         self._enhancer_bwd(dO)
         # ---- Denoise_1 x3
-        dn, dn11, dn12 = self._new(1, H, W, 4), self._new(1, h, w, 4), self._new(1, h, w, 4)
-        lib.call("zt_d1_bwd_prep_f32", v["x"], v["n"], dLp1, dLp2, dden1, dden2, dn, dn11, dn12, 4, H, W, s)
+        la = self.lda
+        dn, dn11, dn12 = self._newa(1, H, W, la), self._newa(1, h, w, la), self._newa(1, h, w, la)
+        lib.call("zt_d1_bwd_prep", v["x"], v["n"], dLp1, dLp2, dden1, dden2, dn, dn11, dn12, self.dt, la, H, W, s)
         self._denoise_bwd(D1, "D1a", dn11, 3, False)
         self._denoise_bwd(D1, "D1b", dn12, 3, False)
         self._denoise_bwd(D1, "D1c", dn, 3, False)

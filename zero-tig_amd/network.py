@@ -173,7 +173,10 @@ class _ZeroTIGBase(nn.Module):
         self.denoise_1 = Denoise_1(chan_embed=48)
         self.denoise_2 = Denoise_2(chan_embed=48)
 
-    def _finish_init(self, args, ops):
+    def _finish_init(self, args, ops, precision=None):
+        import os
+        self.precision = precision or getattr(args, "precision", None) or os.environ.get("ZEROTIG_PRECISION", "fp32")
+        assert self.precision in ("fp32", "bf16")
         self.last_H3 = self.last_H3_wp = self.last_s3 = self.last_s3_wp = None
         self.is_new_seq = True
         self.raft = self.load_raft(args)
@@ -199,7 +202,7 @@ class _ZeroTIGBase(nn.Module):
         """(Re)bind the HIP plans to the current parameter storage (it moves on .cuda()/.to())."""
         tr = self._trainable()
         dev = tr[0][1].device
-        sig = (dev, tuple(p.data_ptr() for _, p in tr), self.raft.fnet.conv1.weight.data_ptr())
+        sig = (dev, tuple(p.data_ptr() for _, p in tr), self.raft.fnet.conv1.weight.data_ptr(), self.precision)
         if self._sig != sig:
             if self._ops is None:
                 if dev.type != "cuda":
@@ -209,7 +212,8 @@ class _ZeroTIGBase(nn.Module):
             bn = self.enhance.conv[1]
             bufs = {"enhance.conv.1.running_mean": bn.running_mean, "enhance.conv.1.running_var": bn.running_var,
                     "enhance.conv.1.num_batches_tracked": bn.num_batches_tracked}
-            self.__dict__["_eng"] = Engine(self._ops, params, bufs, is_WB=getattr(self, "is_WB", False), device=dev)
+            self.__dict__["_eng"] = Engine(self._ops, params, bufs, is_WB=getattr(self, "is_WB", False), device=dev,
+                                           precision=self.precision)
             rw = {"raft." + k: v.data for k, v in self.raft.state_dict().items()}
             self.__dict__["_raftplan"] = RaftPlan(self._ops, rw, dev)
             self.__dict__["_sig"] = sig
@@ -246,12 +250,12 @@ class _ZeroTIGBase(nn.Module):
 class Network(_ZeroTIGBase):
     """Training-time model (model.py:84-259).  `ops` is for tests only (emulated backend); leave None in production."""
 
-    def __init__(self, args, ops=None):
+    def __init__(self, args, ops=None, precision=None):
         super().__init__()
         self._build_nets(args)
         self._l2_loss, self._l1_loss = nn.MSELoss(), nn.L1Loss()
         self.is_WB = "underwater" == args.dataset
-        self._finish_init(args, ops)
+        self._finish_init(args, ops, precision)
 
     def _forward_impl(self, input, keep):
         eng, rp = self._plan()
@@ -298,7 +302,7 @@ class Network(_ZeroTIGBase):
 class Finetunemodel(_ZeroTIGBase):
     """Inference twin (model.py:262-384): full-resolution branch only; returns (H2, H3, s3)."""
 
-    def __init__(self, args, ops=None):
+    def __init__(self, args, ops=None, precision=None):
         super().__init__()
         self._build_nets(args)
         weights = getattr(args, "model_pretrain", None)
@@ -308,7 +312,7 @@ class Finetunemodel(_ZeroTIGBase):
             md = self.state_dict()
             md.update({k: v for k, v in base.items() if k in md})
             self.load_state_dict(md)
-        self._finish_init(args, ops)
+        self._finish_init(args, ops, precision)
 
     weights_init = _ZeroTIGBase.enhance_weights_init
 

@@ -14,19 +14,25 @@ class CV:
     """Channel view of an NHWC fp32 buffer [N,H,W,ld]: channels [off, off+C)."""
 
     def __init__(self, t, off=0, C=None):
-        assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4
+        assert t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous() and t.dim() == 4
         self.t, self.off = t, off
+        self.es = t.element_size()
         self.N, self.H, self.W, self.ld = t.shape
         self.C = self.ld - off if C is None else C
         assert 0 <= off and off + self.C <= self.ld
 
     @property
     def ptr(self):
-        return self.t.data_ptr() + 4 * self.off
+        return self.t.data_ptr() + self.es * self.off
 
 
 def _cv(x):
     return x if isinstance(x, CV) else CV(x)
+
+
+def _dt(t):
+    """storage-type code of the C ABI: 0 = fp32, 1 = bf16"""
+    return 1 if t.dtype == torch.bfloat16 else 0
 
 
 ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "sigmoid": 3, "tanh": 4, "sigmoid_clamp": 5}
@@ -219,7 +225,7 @@ class Ops:
         HW = x.H * x.W
         nblk = self._nblk(HW) if nblk is None else nblk
         part = torch.empty((x.N, nblk, 2, x.C), dtype=torch.float32, device=x.t.device)
-        self.lib.call("zt_chan_stats_nhwc_f32", x.ptr, x.ld, x.N, HW, x.C, nblk, part, self._s(x.t))
+        self.lib.call("zt_chan_stats_nhwc", x.ptr, _dt(x.t), x.ld, x.N, HW, x.C, nblk, part, self._s(x.t))
         return part
 
     def norm_finalize(self, part, N, C, count, mode, gamma=None, beta=None, rm=None, rv=None, nbt=None, momentum=0.1,
@@ -235,10 +241,11 @@ class Ops:
     def norm_apply(self, x, scale, shift, out=None, res=None, inner_relu=False, outer_relu=False):
         x = _cv(x)
         if out is None:
-            out = torch.empty((x.N, x.H, x.W, x.C), dtype=torch.float32, device=x.t.device)
+            out = torch.empty((x.N, x.H, x.W, x.C), dtype=x.t.dtype, device=x.t.device)
         o = _cv(out)
         rp, ldr = (None, 0) if res is None else (_cv(res).ptr, _cv(res).ld)
-        self.lib.call("zt_norm_apply_nhwc_f32", x.ptr, x.ld, scale, shift, rp, ldr, o.ptr, o.ld, x.N, x.H * x.W, x.C,
+        assert o.t.dtype == x.t.dtype and (res is None or _cv(res).t.dtype == x.t.dtype)
+        self.lib.call("zt_norm_apply_nhwc", x.ptr, _dt(x.t), x.ld, scale, shift, rp, ldr, o.ptr, o.ld, x.N, x.H * x.W, x.C,
                       int(inner_relu), int(outer_relu), self._s(x.t))
         return out
 
@@ -251,15 +258,16 @@ class Ops:
         HW, C = z.H * z.W, z.C
         nblk = self._nblk(HW)
         part = torch.empty((nblk, 2, C), dtype=torch.float32, device=z.t.device)
-        self.lib.call("zt_bn_bwd_reduce_f32", dy.ptr, dy.ld, z.ptr, z.ld, scale, shift, mean, rstd, HW, C, nblk, part, self._s(z.t))
+        assert dy.t.dtype == z.t.dtype
+        self.lib.call("zt_bn_bwd_reduce", dy.ptr, _dt(z.t), dy.ld, z.ptr, z.ld, scale, shift, mean, rstd, HW, C, nblk, part, self._s(z.t))
         sums = torch.empty((2, C), dtype=torch.float32, device=z.t.device)
         self.partial_reduce(part, nblk, 2 * C, 2 * C, out=None, out2=sums)
         self.partial_reduce(part, nblk, 2 * C, C, out=dbeta, accumulate=True)
         self.lib.call("zt_partial_reduce_f32", part.data_ptr() + 4 * C, nblk, 2 * C, C, dgamma, 1, None, self._s(z.t))
         if out is None:
-            out = torch.empty((1, z.H, z.W, C), dtype=torch.float32, device=z.t.device)
+            out = torch.empty((1, z.H, z.W, C), dtype=z.t.dtype, device=z.t.device)
         o = _cv(out)
-        self.lib.call("zt_bn_bwd_apply_f32", dy.ptr, dy.ld, z.ptr, z.ld, scale, shift, mean, rstd, sums, o.ptr, o.ld, HW, C, self._s(z.t))
+        self.lib.call("zt_bn_bwd_apply", dy.ptr, _dt(z.t), dy.ld, z.ptr, z.ld, scale, shift, mean, rstd, sums, o.ptr, o.ld, HW, C, self._s(z.t))
         return out
 
     # ---- RAFT specific (zt_raft.hip) --------------------------------------------------------------------------
@@ -303,3 +311,63 @@ class Ops:
         self.lib.call("zt_corr_lookup_f32", corr0, levels[0], levels[1], levels[2], h, w, corr0.shape[-1], coords, out,
                       out.shape[-1], npx, self._s(corr0))
         return out
+
+    # ---- bf16 throughput mode of the convolution family ---------------------------------------------------------
+    def repack_weight_bf16(self, w, transpose_flip=False, out=None):
+        """torch fp32 [Cout,Cin,KH,KW] -> bf16 [KH*KW, CoutP16, ldk8] (input channel fastest); zero padded."""
+        _f32c(w)
+        Cout, Cin, KH, KW = w.shape
+        n_out, n_in = (Cin, Cout) if transpose_flip else (Cout, Cin)
+        CoutP, ldk = (n_out + 15) // 16 * 16, (n_in + 7) // 8 * 8
+        if out is None:
+            out = torch.zeros((KH * KW, CoutP, ldk), dtype=torch.bfloat16, device=w.device)
+        self.lib.call("zt_repack_conv_weight_bf16", w, out, Cout, Cin, KH, KW, CoutP, ldk, int(transpose_flip), self._s(w))
+        return out
+
+    def conv2d_bf16(self, x, wdev, bias, Cout, KH, KW, pad=(0, 0), act=None, alpha=1.0, out=None, out_planar=False, aux=None, epi=0):
+        """x: CV over a bf16 NHWC buffer.  out: bf16 NHWC (CV/tensor) or fp32 planar [N,Cout,Ho,Wo] when out_planar."""
+        x = _cv(x)
+        assert x.t.dtype == torch.bfloat16 and wdev.dtype == torch.bfloat16 and wdev.shape[0] == KH * KW
+        CoutP, ldk = wdev.shape[1], wdev.shape[2]
+        assert ldk >= x.C and CoutP >= Cout
+        Ho, Wo = x.H + 2 * pad[0] - KH + 1, x.W + 2 * pad[1] - KW + 1
+        dev = x.t.device
+        if out_planar:
+            if out is None:
+                out = torch.empty((x.N, Cout, Ho, Wo), dtype=torch.float32, device=dev)
+            yptr, ldy = out.data_ptr(), out.stride(1)
+        else:
+            if out is None:
+                ld = (Cout + 7) // 8 * 8
+                out = torch.empty((x.N, Ho, Wo, ld), dtype=torch.bfloat16, device=dev)
+                if ld != Cout:
+                    out.zero_()
+            o = _cv(out)
+            assert o.t.dtype == torch.bfloat16 and (o.N, o.H, o.W) == (x.N, Ho, Wo) and o.C >= Cout
+            yptr, ldy = o.ptr, o.ld
+        auxp, ldaux = None, 0
+        if epi:
+            av = _cv(aux)
+            assert av.t.dtype == torch.bfloat16
+            auxp, ldaux = av.ptr, av.ld
+        prof = getattr(self, "profile", None)
+        timed = prof is not None and prof["match"] == (KH, KW, 1, x.C, Cout, x.H, x.W)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.lib.call("zt_conv2d_nhwc_bf16", x.ptr, x.ld, x.N, x.H, x.W, x.C, wdev, CoutP, ldk, bias, yptr, ldy, int(out_planar),
+                      Cout, KH, KW, 1, pad[0], pad[1], ACT[act], float(alpha), auxp, ldaux, epi, self._s(x.t))
+        if timed:
+            e1.record()
+            prof["events"].append((e0, e1))
+        return out
+
+    def conv2d_wgrad_bf16(self, x, dz, Cout, KH, KW, grad_w, accumulate=False, slab=None):
+        x, dz = _cv(x), _cv(dz)
+        assert x.t.dtype == torch.bfloat16 and dz.t.dtype == torch.bfloat16
+        assert x.N == 1 and (x.H, x.W) == (dz.H, dz.W) and dz.C >= Cout
+        assert tuple(grad_w.shape) == (Cout, x.C, KH, KW) and grad_w.is_contiguous() and grad_w.dtype == torch.float32
+        slab = self.slab(x.t.device) if slab is None else slab
+        self.lib.call("zt_conv2d_wgrad_nhwc_bf16", x.ptr, x.ld, dz.ptr, dz.ld, x.H, x.W, x.C, Cout, KH, KW, slab, slab.numel() * 4,
+                      grad_w, int(accumulate), self._s(x.t))
+        return grad_w
