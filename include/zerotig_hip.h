@@ -150,21 +150,21 @@ int zt_loss_full_f32(const float* H2b, const float* H3b, const float* s2, const 
 int zt_resize_bilinear_f32(const float* src, float* dst, int C, int H, int W, int h, int w, float mul, zt_stream_t stream);
 /* (x).to(uint8) + per-channel histogram + torchvision==0.18.1 equalize LUT (model.py:234); q: uint8 [C][hw], hist/lut: int32 [C][256] */
 int zt_equalize_prepare_u8(const float* src, unsigned char* q, int* hist, int* lut, int C, int hw, zt_stream_t stream);
-/* raft.py:80-83,132-138: centred replicate pad to multiples of 8, 2*(x/255)-1; frame 1 float, frame 2 = lut[q2]; dst nhwc [2][Hp][Wp][4] */
-int zt_raft_pack_input_f32(const float* img1, const unsigned char* q2, const int* lut, float* dst, int h, int w, int Hp, int Wp, zt_stream_t stream);
+/* raft.py:80-83,132-138: centred replicate pad to multiples of 8, 2*(x/255)-1; frame 1 float, frame 2 = lut[q2]; dst nhwc [2][Hp][Wp][ld] (dt: 0 fp32, 1 bf16) */
+int zt_raft_pack_input(const float* img1, const unsigned char* q2, const int* lut, void* dst, int dt, int ld, int h, int w, int Hp, int Wp, zt_stream_t stream);
 /* the same head for two float frames in [0,255] (RAFT.forward called directly, raft.py:77-83) */
-int zt_raft_pack_pair_f32(const float* img1, const float* img2, float* dst, int h, int w, int Hp, int Wp, zt_stream_t stream);
+int zt_raft_pack_pair(const float* img1, const float* img2, void* dst, int dt, int ld, int h, int w, int Hp, int Wp, zt_stream_t stream);
 /* corr.py:25-27 one pyramid level: avg_pool2d(2,2) of [npx][hin][win] (row pitch ldin) -> [npx][hin/2][win/2] */
 int zt_corr_pool_f32(const float* src, float* dst, int npx, int hin, int win, int ldin, zt_stream_t stream);
 /* corr.py:29-50 (the seam of alt_cuda_corr.forward, corr.py:86): coords [npx][2] -> out nhwc [npx][ldo>=324], channel = lvl*81 + i*9 + j */
-int zt_corr_lookup_f32(const float* l0, const float* l1, const float* l2, const float* l3, int h, int w, int ld0, const float* coords,
-                       float* out, int ldo, int npx, zt_stream_t stream);
+int zt_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, int h, int w, int ld0, const float* coords,
+                   void* out, int dt, int ldo, int npx, zt_stream_t stream);
 /* update.py:42-45: rh = r*h with zr = [z|r]; update.py:47: h = (1-z)h + z q */
-int zt_gru_rh_f32(const float* zr, int ldzr, const float* hbuf, int ldh, float* rh, int ldrh, int C, int npx, zt_stream_t stream);
-int zt_gru_update_f32(const float* zr, int ldzr, const float* q, int ldq, float* hbuf, int ldh, int C, int npx, zt_stream_t stream);
-/* raft.py:57-62,112-120: coords grid; coords1 += delta (may be NULL), flow = coords1 - coords0 written to two nhwc destinations */
+int zt_gru_rh(const void* zr, int dt, int ldzr, const void* hbuf, int ldh, void* rh, int ldrh, int C, int npx, zt_stream_t stream);
+int zt_gru_update(const void* zr, int dt, int ldzr, const void* q, int ldq, void* hbuf, int ldh, int C, int npx, zt_stream_t stream);
+/* raft.py:57-62,112-120: coords grid; coords1 += delta (may be NULL), flow = coords1 - coords0 written to f4 (fp32) and to up to two nhwc destinations of storage type dt */
 int zt_raft_coords_init_f32(float* coords, int h, int w, zt_stream_t stream);
-int zt_raft_flow_step_f32(float* coords1, const float* delta, int ldd, int h, int w, float* f4, int ldf4, float* fhx, int ldfhx, zt_stream_t stream);
+int zt_raft_flow_step(float* coords1, const float* delta, int ldd, int h, int w, float* f4, int ldf4, void* fhx, int ldfhx, void* fin, int ldfin, int dt, zt_stream_t stream);
 /* raft.py:64-75 upsample_flow: flow nhwc (ldf), mask nhwc [npx][576] -> planar [2][8h][8w]; optional planar flow_low [2][h][w] */
 int zt_convex_upsample_f32(const float* f4, int ldf, const float* mask, int ldm, float* up, float* flow_low, int h, int w, zt_stream_t stream);
 
@@ -183,15 +183,15 @@ int zt_probe_tr16(const unsigned short* img, unsigned short* out, int col0, zt_s
 int zt_probe_mfma_bf16(const unsigned short* A, const unsigned short* B, float* D, zt_stream_t stream);
 
 
-/* ---- bf16 throughput mode of the convolution family: x / y / aux / dz are bf16 nhwc (channel strides multiples of 8), w is
- * bf16 [tap][CoutP][ldk] (input channel fastest), accumulation fp32; y may instead be fp32 planar (thin output layers).
- * Supported (KH,KW,stride): (3,3,1), (1,1,1) -- the enhancement / denoising nets.  Same act / alpha / epi semantics. */
-int zt_conv2d_nhwc_bf16(const void* x, int ldx, int N, int H, int W, int Cin, const void* w, int CoutP, int ldk, const float* bias,
-                        void* y, int ldy, int out_f32_planar, int Cout, int KH, int KW, int stride, int padH, int padW, int act,
-                        float alpha, const void* aux, int ldaux, int epi, zt_stream_t stream);
+/* ---- bf16 throughput mode of the convolution family: x / x2 / aux / dz are bf16 nhwc (channel strides multiples of 8), w is
+ * bf16 [tap][CoutP][ldk] (input channel fastest; the all-pairs correlation passes fmap2 itself, nhwc, as w), accumulation fp32.
+ * out_mode: 0 = bf16 nhwc, 1 = fp32 planar (plane pitch ldy), 2 = fp32 nhwc.  Same geometries / act / alpha / epi as the fp32 entry. */
+int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin, const void* w,
+                        int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout, int KH, int KW, int stride,
+                        int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi, zt_stream_t stream);
 int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout, int KH, int KW,
                               float* slab, size_t slab_bytes, float* grad_w, int accumulate, zt_stream_t stream);
-int zt_repack_conv_weight_bf16(const float* src, void* dst, int Cout, int Cin, int KH, int KW, int CoutP, int ldk,
+int zt_repack_conv_weight_bf16(const float* src, void* dst, int Cout, int Cin, int KH, int KW, int CoutP, int ldk, int co_off,
                                int transpose_flip, zt_stream_t stream);
 
 #ifdef __cplusplus

@@ -203,3 +203,24 @@ def test_bf16_mode_psnr_gate(backend, synth, oracle):
     for n, p in net.named_parameters():
         if p.requires_grad and not n.startswith("enhance.blocks") and n != "enhance.conv.0.bias":
             assert rel_l2(p.grad, g["grad:" + n]) < 6e-2, (n, rel_l2(p.grad, g["grad:" + n]))
+
+
+def test_bf16_sequence_flow_and_psnr(backend, synth, oracle):
+    """Throughput mode through RAFT + warp: flow stays close to the fp32 reference flow, and the enhanced second frame passes
+    the PSNR gate (|dPSNR| <= 0.01 dB vs the reference output, evals.py:83-85 definition against the clean frame)."""
+    ops, dev, bname = backend
+    _skip_heavy_emu(bname)
+    g = load_golden("g3_seq_128x160")
+    H, W, seed, ofs = [int(v) for v in g["meta"]]
+    xs = [f.to(dev) for f in frames(synth, 2, H, W)]
+    net = _network(ops, dev, synth, seed, of_scale=ofs, precision="bf16").train()
+    net.is_new_seq = True
+    net._loss(xs[0])
+    net.is_new_seq = False
+    l1 = net._loss(xs[1])
+    clean = torch.from_numpy(synth.clean_frame(1, H, W)).float()[None]
+    H3, ref = net.last_H3.cpu(), torch.from_numpy(g["last_H3"])
+    assert abs(oracle.psnr_u8(H3, clean) - oracle.psnr_u8(ref, clean)) <= 0.01
+    assert abs(float(l1) - float(g["loss1"])) <= 2e-2 * abs(float(g["loss1"]))
+    wp_err = float((net.last_H3_wp.cpu() - torch.from_numpy(g["wpH"])).abs().mean())
+    assert wp_err < 5e-3, wp_err

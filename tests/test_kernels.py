@@ -388,3 +388,66 @@ def test_conv_wgrad_bf16(backend, case):
     gw = torch.full((Cout, Cin, K, K), 3.0, device=dev)
     ops.conv2d_wgrad_bf16(CV(_nhwc_bf16(x, ldx).to(dev), 0, Cin), CV(_nhwc_bf16(dz, lddz).to(dev), 0, Cout), Cout, K, K, gw)
     assert maxerr(gw, w.grad) < 2e-3 * float(w.grad.abs().max()), maxerr(gw, w.grad)
+
+
+BF16_GEO = [
+    # Cin, Cout, KH, KW, stride, pad, H, W, act, ld
+    (3, 64, 7, 7, 2, (3, 3), 20, 36, None, 8),
+    (64, 96, 3, 3, 2, (1, 1), 11, 21, "relu", 64),
+    (64, 96, 1, 1, 2, (0, 0), 11, 21, None, 64),
+    (40, 32, 1, 5, 1, (0, 2), 6, 18, "sigmoid", 40),
+    (40, 32, 5, 1, 1, (2, 0), 6, 18, "tanh", 40),
+    (2, 128, 7, 7, 1, (3, 3), 6, 10, "relu", 8),
+    (324, 256, 1, 1, 1, (0, 0), 5, 9, "relu", 328),
+    (256, 126, 3, 3, 1, (1, 1), 9, 40, "relu", 256),     # wide enough to take the MT=2 path as well
+]
+
+
+@pytest.mark.parametrize("case", BF16_GEO, ids=lambda c: "c%d-%d_k%dx%d_s%d" % c[:5])
+def test_conv_bf16_raft_geometries(backend, case):
+    import torch.nn.functional as F
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    Cin, Cout, KH, KW, stride, pad, H, W, act, ld = case
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    N = 2 if KH == 7 and stride == 2 else 1
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w.bfloat16().float(), b, stride=stride, padding=pad)
+    ref = {None: lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](ref)
+    xd = _nhwc_bf16(x, ld).to(dev)
+    wd = ops.repack_weight_bf16(w.to(dev))
+    y = ops.conv2d_bf16(CV(xd, 0, Cin), wd, b.to(dev), Cout, KH, KW, pad, act, stride=stride, out_f32=True)
+    got = y.cpu()[..., :Cout].permute(0, 3, 1, 2)
+    assert maxerr(got, ref) < 5e-4 * max(1.0, float(ref.abs().max())), maxerr(got, ref)
+
+
+def test_conv_bf16_split_input_and_row_offset(backend):
+    import torch.nn.functional as F
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    g = torch.Generator().manual_seed(9)
+    H, W = 5, 21
+    xa = torch.randn(1, 32, H, W, generator=g).bfloat16().float()
+    xb = torch.randn(1, 24, H, W, generator=g).bfloat16().float()
+    w = torch.randn(48, 56, 1, 5, generator=g) * 0.05
+    ref = 0.25 * F.conv2d(torch.cat([xa, xb], 1), w.bfloat16().float(), None, padding=(0, 2))
+    big = torch.zeros(1, H, W, 64)
+    big[..., 8:32] = _nhwc(xb)
+    wd = ops.repack_weight_bf16(w.to(dev))
+    out = torch.zeros(1, H, W, 64, dtype=torch.bfloat16, device=dev)
+    ops.conv2d_bf16(CV(_nhwc_bf16(xa, 32).to(dev)), wd, None, 48, 1, 5, (0, 2), None, alpha=0.25, x2=CV(big.bfloat16().to(dev), 8, 24),
+                    out=CV(out, 16, 48))
+    got = out.float().cpu()[..., 16:64].permute(0, 3, 1, 2)
+    assert float(((got - ref).abs() - ref.abs() * 2 ** -8).max()) < 2e-3
+    assert float(out[..., :16].float().abs().max()) == 0.0
+    # 1x1 with an output-row offset into the weight matrix (the cnet tanh / relu split)
+    w1 = torch.randn(64, 32, 1, 1, generator=g) * 0.2
+    b1 = torch.randn(64, generator=g)
+    ref1 = torch.relu(F.conv2d(xa, w1.bfloat16().float(), b1))[:, 32:]
+    wd1 = ops.repack_weight_bf16(w1.to(dev))
+    y1 = ops.conv2d_bf16(CV(_nhwc_bf16(xa, 32).to(dev)), wd1, b1[32:].contiguous().to(dev), 32, 1, 1, (0, 0), "relu", w_roff=32, out_f32=True)
+    assert maxerr(y1.cpu().permute(0, 3, 1, 2), ref1) < 1e-3

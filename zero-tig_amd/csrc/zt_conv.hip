@@ -349,25 +349,31 @@ int launch_wgrad(const WgradArgs& a, int CT, int NT, int nblk, hipStream_t strea
 // =====================================================================================================================
 struct ConvArgsH {
   const zt_bf16* x;
+  const zt_bf16* x2;
   const zt_bf16* w;
   const float* bias;
   const zt_bf16* aux;
   void* y;
-  int N, H, W, Cin, ldx;
+  int N, H, W, Cin, ldx, ldx2, csplit;
   int Ho, Wo, Cout, CoutP, ldk, ldy, ldaux;
   int padH, padW;
-  int act, epi, out_f32_planar;
+  int act, epi, out_mode;      // out_mode: 0 bf16 nhwc, 1 fp32 planar, 2 fp32 nhwc
   float alpha;
   int tilesX, tilesY;
 };
 
 constexpr int HCK = 32, HCKP = 40;
 
-template <int KH, int KW, int S, int NT>
+// ALL: every tap's weights of the current 32-channel chunk fit in LDS next to the input tile -> 2 barriers per chunk;
+// otherwise weights are staged per kernel row (7x7).  MT = 16-pixel MFMA tiles per wave along x (1 for small feature maps).
+template <int KH, int KW, int S, int NT, int MT, bool ALL>
 __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
-  constexpr int IR = (TH - 1) * S + KH, IC = (TW - 1) * S + KW;
+  constexpr int TWm = 16 * MT;
+  constexpr int IR = (TH - 1) * S + KH, IC = (TWm - 1) * S + KW;
+  constexpr int TG = ALL ? KH * KW : KW;          // taps staged together
+  constexpr int NG = ALL ? 1 : KH;
   __shared__ __attribute__((aligned(16))) zt_bf16 xs[IR * IC * HCKP];
-  __shared__ __attribute__((aligned(16))) zt_bf16 ws[KW * NT * 16 * HCKP];
+  __shared__ __attribute__((aligned(16))) zt_bf16 ws[TG * NT * 16 * HCKP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int t = blockIdx.x;
@@ -376,64 +382,73 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
   const int ty = t % a.tilesY;
   const int n = t / a.tilesY;
   const int co0 = blockIdx.y * (NT * 16);
-  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int oy0 = ty * TH, ox0 = tx * TWm;
   const int gy0 = oy0 * S - a.padH, gx0 = ox0 * S - a.padW;
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  zt_f32x4 acc[2][NT];
+  zt_f32x4 acc[MT][NT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int q = 0; q < NT; ++q) acc[m][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int c0 = 0; c0 < a.Cin; c0 += HCK) {
     __syncthreads();
-    for (int e = tid; e < IR * IC * 4; e += 256) {
-      int p = e >> 2, q = e & 3;
-      int iy = p / IC, ixx = p - iy * IC;
-      int gy = gy0 + iy, gx = gx0 + ixx;
-      int c = c0 + q * 8;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Cin) {
-        const zt_bf16* g = a.x + ((size_t)(n * a.H + gy) * a.W + gx) * a.ldx + c;
-        v = *reinterpret_cast<const uint4*>(g);
-        if (c + 8 > a.Cin) {            // ragged tail: keep only the valid channels
-          zt_bf16 tmp[8];
-          __builtin_memcpy(tmp, &v, 16);
-          for (int j = 0; j < 8; ++j)
-            if (c + j >= a.Cin) tmp[j] = 0;
-          __builtin_memcpy(&v, tmp, 16);
+    {
+      const bool second = a.x2 != nullptr && c0 >= a.csplit;
+      const zt_bf16* src = second ? a.x2 : a.x;
+      const int ld = second ? a.ldx2 : a.ldx;
+      const int cbase = second ? c0 - a.csplit : c0;
+      const int climit = second ? a.Cin - a.csplit : (a.x2 ? a.csplit : a.Cin);
+      for (int e = tid; e < IR * IC * 4; e += 256) {
+        int p = e >> 2, q = e & 3;
+        int iy = p / IC, ixx = p - iy * IC;
+        int gy = gy0 + iy, gx = gx0 + ixx;
+        int c = cbase + q * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < climit) {
+          const zt_bf16* g = src + ((size_t)(n * a.H + gy) * a.W + gx) * ld + c;
+          v = *reinterpret_cast<const uint4*>(g);
+          if (c + 8 > climit) {            // ragged tail: keep only the valid channels
+            zt_bf16 tmp[8];
+            __builtin_memcpy(tmp, &v, 16);
+            for (int j = 0; j < 8; ++j)
+              if (c + j >= climit) tmp[j] = 0;
+            __builtin_memcpy(&v, tmp, 16);
+          }
         }
+        *reinterpret_cast<uint4*>(xs + p * HCKP + q * 8) = v;
       }
-      *reinterpret_cast<uint4*>(xs + p * HCKP + q * 8) = v;
     }
 #pragma unroll 1
-    for (int ky = 0; ky < KH; ++ky) {
-      for (int e = tid; e < KW * NT * 16 * 4; e += 256) {
+    for (int grp = 0; grp < NG; ++grp) {
+      if (grp > 0) __syncthreads();
+      for (int e = tid; e < TG * NT * 16 * 4; e += 256) {
         int q = e & 3;
         int r = e >> 2;
-        int co = r % (NT * 16), kx = r / (NT * 16);
+        int co = r % (NT * 16), tl = r / (NT * 16);
+        int tap = grp * TG + tl;
         int c = c0 + q * 8;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (c < a.ldk && co0 + co < a.CoutP)
-          v = *reinterpret_cast<const uint4*>(a.w + ((size_t)(ky * KW + kx) * a.CoutP + co0 + co) * a.ldk + c);
-        *reinterpret_cast<uint4*>(ws + (kx * NT * 16 + co) * HCKP + q * 8) = v;
+          v = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.CoutP + co0 + co) * a.ldk + c);
+        *reinterpret_cast<uint4*>(ws + (tl * NT * 16 + co) * HCKP + q * 8) = v;
       }
       __syncthreads();
 #pragma unroll
-      for (int kx = 0; kx < KW; ++kx) {
-        zt_s16x8 av[2], bv[NT];
+      for (int tl = 0; tl < TG; ++tl) {
+        const int ky = ALL ? tl / KW : grp, kx = ALL ? tl % KW : tl;
+        zt_s16x8 av[MT], bv[NT];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
           av[m] = *reinterpret_cast<const zt_s16x8*>(xs + ((wave * S + ky) * IC + (m * 16 + l15) * S + kx) * HCKP + 8 * l4);
 #pragma unroll
-        for (int q = 0; q < NT; ++q) bv[q] = *reinterpret_cast<const zt_s16x8*>(ws + (kx * NT * 16 + q * 16 + l15) * HCKP + 8 * l4);
+        for (int q = 0; q < NT; ++q) bv[q] = *reinterpret_cast<const zt_s16x8*>(ws + (tl * NT * 16 + q * 16 + l15) * HCKP + 8 * l4);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(av[m], bv[q], acc[m][q]);
       }
-      __syncthreads();
     }
   }
 
@@ -445,7 +460,7 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
     if (co >= a.Cout) continue;
     const float b = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ox = ox0 + m * 16 + l4 * 4 + j;
@@ -458,24 +473,32 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
           else if (a.epi == 2) v *= (u > 0.f ? 1.f : 0.f);
           else v += u;
         }
-        if (a.out_f32_planar) ((float*)a.y)[((size_t)n * a.Cout + co) * a.ldy + (size_t)oy * a.Wo + ox] = v;
+        if (a.out_mode == 1) ((float*)a.y)[((size_t)n * a.Cout + co) * a.ldy + (size_t)oy * a.Wo + ox] = v;
+        else if (a.out_mode == 2) ((float*)a.y)[pix * a.ldy + co] = v;
         else ((zt_bf16*)a.y)[pix * a.ldy + co] = zt_f2bf(v);
       }
     }
   }
 }
 
-template <int KH, int KW, int S>
-int launch_conv_h(const ConvArgsH& a, int NT, dim3 grid_base, hipStream_t stream) {
+template <int KH, int KW, int S, int MT>
+int launch_conv_h(const ConvArgsH& a, int NT, unsigned gx, hipStream_t stream) {
   dim3 block(256);
   int c16 = (a.Cout + 15) / 16;
-  dim3 grid(grid_base.x, (c16 + NT - 1) / NT);
-  switch (NT) {
-    case 1: hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, 1>), grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, 2>), grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, 3>), grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, 4>), grid, block, 0, stream, a); break;
+  dim3 grid(gx, (c16 + NT - 1) / NT);
+  constexpr int IRc = (TH - 1) * S + KH, ICc = (16 * MT - 1) * S + KW;
+#define ZT_CH(nt)                                                                                             \
+  {                                                                                                           \
+    constexpr bool all = (KH * KW * nt * 16 + IRc * ICc) * HCKP * 2 <= 64 * 1024;                             \
+    hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all>), grid, block, 0, stream, a);           \
   }
+  switch (NT) {
+    case 1: ZT_CH(1) break;
+    case 2: ZT_CH(2) break;
+    case 3: ZT_CH(3) break;
+    default: ZT_CH(4) break;
+  }
+#undef ZT_CH
   return 0;
 }
 
@@ -610,8 +633,8 @@ int launch_wgrad_h(const WgradArgsH& a, int CT, int NT, int nblk, hipStream_t st
 
 // torch fp32 [Cout][Cin][KH][KW] -> bf16 [tap][CoutP][ldk] (input channel fastest); transpose_flip: the data-gradient operator
 __global__ void __launch_bounds__(256) repack_w_bf16_kernel(const float* __restrict__ src, zt_bf16* __restrict__ dst, int Cout,
-                                                            int Cin, int KH, int KW, int CoutP, int ldk, int transpose_flip,
-                                                            int total) {
+                                                            int Cin, int KH, int KW, int CoutP, int ldk, int co_off,
+                                                            int transpose_flip, int total) {
   int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   int kx = idx % KW;
@@ -619,8 +642,8 @@ __global__ void __launch_bounds__(256) repack_w_bf16_kernel(const float* __restr
   int ci = (idx / (KW * KH)) % Cin;
   int co = idx / (KW * KH * Cin);
   zt_bf16 v = zt_f2bf(src[idx]);
-  if (!transpose_flip) dst[((size_t)(ky * KW + kx) * CoutP + co) * ldk + ci] = v;
-  else dst[((size_t)((KH - 1 - ky) * KW + (KW - 1 - kx)) * CoutP + ci) * ldk + co] = v;
+  if (!transpose_flip) dst[((size_t)(ky * KW + kx) * CoutP + co_off + co) * ldk + ci] = v;
+  else dst[((size_t)((KH - 1 - ky) * KW + (KW - 1 - kx)) * CoutP + co_off + ci) * ldk + co] = v;
 }
 
 // torch [Cout][Cin][KH][KW] -> device [tap][Cin'][ldw] (forward) or the data-gradient form
@@ -711,29 +734,38 @@ extern "C" int zt_repack_conv_weight_f32(const float* src, float* dst, int Cout,
   return ZT_OK;
 }
 
-extern "C" int zt_conv2d_nhwc_bf16(const void* x, int ldx, int N, int H, int W, int Cin, const void* w, int CoutP, int ldk,
-                                   const float* bias, void* y, int ldy, int out_f32_planar, int Cout, int KH, int KW, int stride,
-                                   int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi,
-                                   hipStream_t stream) {
-  ZT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
-  ZT_REQUIRE(ldx % 8 == 0 && ldk % 8 == 0 && CoutP % 16 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
+extern "C" int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
+                                   const void* w, int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout,
+                                   int KH, int KW, int stride, int padH, int padW, int act, float alpha, const void* aux,
+                                   int ldaux, int epi, hipStream_t stream) {
+  ZT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && out_mode >= 0 && out_mode <= 2);
+  ZT_REQUIRE(ldx % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
+  ZT_REQUIRE(!x2 || (csplit % HCK == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0));
   ZT_REQUIRE(epi == 0 || aux);
   ConvArgsH a;
-  a.x = (const zt_bf16*)x; a.w = (const zt_bf16*)w; a.bias = bias; a.aux = (const zt_bf16*)aux; a.y = y;
-  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx;
+  a.x = (const zt_bf16*)x; a.x2 = (const zt_bf16*)x2; a.w = (const zt_bf16*)w; a.bias = bias; a.aux = (const zt_bf16*)aux; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.ldx2 = ldx2; a.csplit = csplit;
   a.Ho = (H + 2 * padH - KH) / stride + 1;
   a.Wo = (W + 2 * padW - KW) / stride + 1;
   a.Cout = Cout; a.CoutP = CoutP; a.ldk = ldk; a.ldy = ldy; a.ldaux = ldaux;
-  a.padH = padH; a.padW = padW; a.act = act; a.epi = epi; a.out_f32_planar = out_f32_planar; a.alpha = alpha;
-  a.tilesX = zt_cdiv(a.Wo, TW);
-  a.tilesY = zt_cdiv(a.Ho, TH);
+  a.padH = padH; a.padW = padW; a.act = act; a.epi = epi; a.out_mode = out_mode; a.alpha = alpha;
   ZT_REQUIRE(a.Ho > 0 && a.Wo > 0);
+  a.tilesY = zt_cdiv(a.Ho, TH);
   int c16 = (Cout + 15) / 16;
   int NT = c16 >= 4 ? ((c16 % 4 == 0) ? 4 : (c16 % 3 == 0 ? 3 : 4)) : c16;
-  dim3 gb((unsigned)(a.tilesX * a.tilesY * N));
+  // small feature maps (RAFT at 1/8 resolution): narrower tiles / fewer channels per workgroup so that >= ~2 workgroups per CU exist
+  int MT = 2;
+  long long wgs = (long long)zt_cdiv(a.Wo, 32) * a.tilesY * N * zt_cdiv(c16, NT);
+  if (wgs < 512 || stride == 2) MT = 1;
+  if (MT == 1 && NT == 4 && (long long)zt_cdiv(a.Wo, 16) * a.tilesY * N * zt_cdiv(c16, NT) < 512 && c16 % 2 == 0) NT = 2;
+  a.tilesX = zt_cdiv(a.Wo, 16 * MT);
+  unsigned gx = (unsigned)(a.tilesX * a.tilesY * N);
   int rc = ZT_EINVAL;
-  if (KH == 3 && KW == 3 && stride == 1) rc = launch_conv_h<3, 3, 1>(a, NT, gb, stream);
-  else if (KH == 1 && KW == 1 && stride == 1) rc = launch_conv_h<1, 1, 1>(a, NT, gb, stream);
+#define ZT_GEO(kh, kw, st)                                                        \
+  if (KH == kh && KW == kw && stride == st)                                       \
+    rc = (MT == 2) ? launch_conv_h<kh, kw, st, 2>(a, NT, gx, stream) : launch_conv_h<kh, kw, st, 1>(a, NT, gx, stream);
+  ZT_GEO(3, 3, 1) ZT_GEO(3, 3, 2) ZT_GEO(1, 1, 1) ZT_GEO(1, 1, 2) ZT_GEO(1, 5, 1) ZT_GEO(5, 1, 1) ZT_GEO(7, 7, 1) ZT_GEO(7, 7, 2)
+#undef ZT_GEO
   if (rc) return rc;
   ZT_LAUNCH_CHECK();
   return ZT_OK;
@@ -766,11 +798,11 @@ extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
 }
 
 extern "C" int zt_repack_conv_weight_bf16(const float* src, void* dst, int Cout, int Cin, int KH, int KW, int CoutP, int ldk,
-                                          int transpose_flip, hipStream_t stream) {
+                                          int co_off, int transpose_flip, hipStream_t stream) {
   ZT_REQUIRE(src && dst && CoutP % 16 == 0 && ldk % 8 == 0);
   int total = Cout * Cin * KH * KW;
   hipLaunchKernelGGL(repack_w_bf16_kernel, dim3(zt_cdiv(total, 256)), dim3(256), 0, stream, src, (zt_bf16*)dst, Cout, Cin, KH, KW,
-                     CoutP, ldk, transpose_flip, total);
+                     CoutP, ldk, co_off, transpose_flip, total);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

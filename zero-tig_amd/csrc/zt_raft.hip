@@ -99,40 +99,46 @@ __global__ void equalize_lut_kernel(const int* __restrict__ hist, int* __restric
 
 // RAFT.forward head (raft.py:80-83, 132-138): centred replicate pad to /8 and 2*(x/255)-1, both frames into one NHWC4
 // batch [2][Hp][Wp][4]; frame 2 goes through the equalisation LUT.
+template <typename T>
+__device__ __forceinline__ void store_px(T* __restrict__ d, int ld, float a, float b, float c) {
+  ZtIO<T>::st(d + 0, a);
+  ZtIO<T>::st(d + 1, b);
+  ZtIO<T>::st(d + 2, c);
+  for (int k = 3; k < ld; ++k) ZtIO<T>::st(d + k, 0.f);
+}
+
+template <typename T>
 __global__ void __launch_bounds__(256) raft_pack_kernel(const float* __restrict__ img1, const unsigned char* __restrict__ q2,
-                                                        const int* __restrict__ lut, float* __restrict__ dst, int h, int w,
+                                                        const int* __restrict__ lut, T* __restrict__ dst, int ld, int h, int w,
                                                         int Hp, int Wp, int top, int left) {
   int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= Wp || y >= Hp) return;
   int sy = min(max(y - top, 0), h - 1), sx = min(max(x - left, 0), w - 1);
   size_t so = (size_t)sy * w + sx;
-  float4 a, b;
   float v[3], u[3];
   for (int c = 0; c < 3; ++c) {
     v[c] = 2.f * (img1[(size_t)c * h * w + so] / 255.f) - 1.f;
     float e = (float)lut[c * 256 + q2[(size_t)c * h * w + so]];
     u[c] = 2.f * (e / 255.f) - 1.f;
   }
-  a = make_float4(v[0], v[1], v[2], 0.f);
-  b = make_float4(u[0], u[1], u[2], 0.f);
-  size_t o = ((size_t)y * Wp + x) * 4;
-  *reinterpret_cast<float4*>(dst + o) = a;
-  *reinterpret_cast<float4*>(dst + (size_t)Hp * Wp * 4 + o) = b;
+  size_t o = ((size_t)y * Wp + x) * ld;
+  store_px<T>(dst + o, ld, v[0], v[1], v[2]);
+  store_px<T>(dst + (size_t)Hp * Wp * ld + o, ld, u[0], u[1], u[2]);
 }
 
 // same head for two float frames (RAFT.forward called directly, raft.py:77-83)
+template <typename T>
 __global__ void __launch_bounds__(256) raft_pack_pair_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
-                                                             float* __restrict__ dst, int h, int w, int Hp, int Wp, int top,
+                                                             T* __restrict__ dst, int ld, int h, int w, int Hp, int Wp, int top,
                                                              int left) {
   int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= Wp || y >= Hp) return;
   int sy = min(max(y - top, 0), h - 1), sx = min(max(x - left, 0), w - 1);
   size_t so = (size_t)sy * w + sx, hw = (size_t)h * w;
-  float4 a = make_float4(2.f * (img1[so] / 255.f) - 1.f, 2.f * (img1[hw + so] / 255.f) - 1.f, 2.f * (img1[2 * hw + so] / 255.f) - 1.f, 0.f);
-  float4 b = make_float4(2.f * (img2[so] / 255.f) - 1.f, 2.f * (img2[hw + so] / 255.f) - 1.f, 2.f * (img2[2 * hw + so] / 255.f) - 1.f, 0.f);
-  size_t o = ((size_t)y * Wp + x) * 4;
-  *reinterpret_cast<float4*>(dst + o) = a;
-  *reinterpret_cast<float4*>(dst + (size_t)Hp * Wp * 4 + o) = b;
+  size_t o = ((size_t)y * Wp + x) * ld;
+  store_px<T>(dst + o, ld, 2.f * (img1[so] / 255.f) - 1.f, 2.f * (img1[hw + so] / 255.f) - 1.f, 2.f * (img1[2 * hw + so] / 255.f) - 1.f);
+  store_px<T>(dst + (size_t)Hp * Wp * ld + o, ld, 2.f * (img2[so] / 255.f) - 1.f, 2.f * (img2[hw + so] / 255.f) - 1.f,
+              2.f * (img2[2 * hw + so] / 255.f) - 1.f);
 }
 
 // corr.py:25-27: avg_pool2d(2, stride 2) over the (h2, w2) axes of [npx][hin][win] -> [npx][hin/2][win/2]
@@ -152,12 +158,13 @@ struct LookupArgs {
   const float* lvl[4];
   int h[4], w[4], ld[4];
   const float* coords;      // [npx][2] (x, y)
-  float* out;               // [npx][ldo]
+  void* out;                // [npx][ldo], fp32 or bf16
   int npx, ldo;
 };
 
 // corr.py:29-50 + utils.py:285-299: 4 levels x 9x9 window, bilinear, align_corners=True, zeros padding.
 // channel = level*81 + i*9 + j with the FIRST window axis (i) moving x (corr.py:37-43).
+template <typename T>
 __global__ void __launch_bounds__(256) corr_lookup_kernel(LookupArgs a) {
   long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= (long long)a.npx * 324) return;
@@ -182,34 +189,37 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(LookupArgs a) {
   v = fmaf(ZT_TAP(x0, y0 + 1), wx0 * wy1, v);
   v = fmaf(ZT_TAP(x0 + 1, y0 + 1), wx1 * wy1, v);
 #undef ZT_TAP
-  a.out[(size_t)n * a.ldo + ch] = v;
+  ZtIO<T>::st((T*)a.out + (size_t)n * a.ldo + ch, v);
 }
 
 // update.py:42-45, 50-53: rh = r * h  (zr = [z | r] after the sigmoid)
-__global__ void __launch_bounds__(256) gru_rh_kernel(const float* __restrict__ zr, int ldzr, const float* __restrict__ hbuf,
-                                                     int ldh, float* __restrict__ rh, int ldrh, int C, long long total) {
+template <typename T>
+__global__ void __launch_bounds__(256) gru_rh_kernel(const T* __restrict__ zr, int ldzr, const T* __restrict__ hbuf,
+                                                     int ldh, T* __restrict__ rh, int ldrh, int C, long long total) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   int c = (int)(i % C);
   long long p = i / C;
-  rh[p * ldrh + c] = zr[p * ldzr + C + c] * hbuf[p * ldh + c];
+  ZtIO<T>::st(rh + p * ldrh + c, ZtIO<T>::ld(zr + p * ldzr + C + c) * ZtIO<T>::ld(hbuf + p * ldh + c));
 }
 
 // h = (1 - z) * h + z * q
-__global__ void __launch_bounds__(256) gru_update_kernel(const float* __restrict__ zr, int ldzr, const float* __restrict__ q,
-                                                         int ldq, float* __restrict__ hbuf, int ldh, int C, long long total) {
+template <typename T>
+__global__ void __launch_bounds__(256) gru_update_kernel(const T* __restrict__ zr, int ldzr, const T* __restrict__ q,
+                                                         int ldq, T* __restrict__ hbuf, int ldh, int C, long long total) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   int c = (int)(i % C);
   long long p = i / C;
-  float z = zr[p * ldzr + c], hv = hbuf[p * ldh + c];
-  hbuf[p * ldh + c] = (1.f - z) * hv + z * q[p * ldq + c];
+  float z = ZtIO<T>::ld(zr + p * ldzr + c), hv = ZtIO<T>::ld(hbuf + p * ldh + c);
+  ZtIO<T>::st(hbuf + p * ldh + c, (1.f - z) * hv + z * ZtIO<T>::ld(q + p * ldq + c));
 }
 
 // raft.py:112-120: coords1 += delta_flow; flow = coords1 - coords0.  Writes flow to two NHWC destinations.
+template <typename T>
 __global__ void __launch_bounds__(256) flow_step_kernel(float* __restrict__ coords1, const float* __restrict__ delta, int ldd,
                                                         int w, int npx, float* __restrict__ f4, int ldf4,
-                                                        float* __restrict__ fhx, int ldfhx) {
+                                                        T* __restrict__ fhx, int ldfhx, T* __restrict__ fin, int ldfin) {
   int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= npx) return;
   float x0 = (float)(n % w), y0 = (float)(n / w);
@@ -224,8 +234,12 @@ __global__ void __launch_bounds__(256) flow_step_kernel(float* __restrict__ coor
   f4[(size_t)n * ldf4 + 0] = fx;
   f4[(size_t)n * ldf4 + 1] = fy;
   if (fhx) {
-    fhx[(size_t)n * ldfhx + 0] = fx;
-    fhx[(size_t)n * ldfhx + 1] = fy;
+    ZtIO<T>::st(fhx + (size_t)n * ldfhx + 0, fx);
+    ZtIO<T>::st(fhx + (size_t)n * ldfhx + 1, fy);
+  }
+  if (fin) {
+    ZtIO<T>::st(fin + (size_t)n * ldfin + 0, fx);
+    ZtIO<T>::st(fin + (size_t)n * ldfin + 1, fy);
   }
 }
 
@@ -307,21 +321,23 @@ extern "C" int zt_equalize_prepare_u8(const float* src, unsigned char* q, int* h
   return ZT_OK;
 }
 
-extern "C" int zt_raft_pack_input_f32(const float* img1, const unsigned char* q2, const int* lut, float* dst, int h, int w,
-                                      int Hp, int Wp, hipStream_t stream) {
-  ZT_REQUIRE(img1 && q2 && lut && dst && Hp >= h && Wp >= w && Hp % 8 == 0 && Wp % 8 == 0 && Hp - h < 8 && Wp - w < 8);
+extern "C" int zt_raft_pack_input(const float* img1, const unsigned char* q2, const int* lut, void* dst, int dt, int ld, int h,
+                                  int w, int Hp, int Wp, hipStream_t stream) {
+  ZT_REQUIRE(img1 && q2 && lut && dst && Hp >= h && Wp >= w && Hp % 8 == 0 && Wp % 8 == 0 && Hp - h < 8 && Wp - w < 8 && ld >= 3);
   int top = (Hp - h) / 2, left = (Wp - w) / 2;
-  hipLaunchKernelGGL(raft_pack_kernel, dim3(zt_cdiv(Wp, 64), zt_cdiv(Hp, 4)), dim3(64, 4), 0, stream, img1, q2, lut, dst, h, w,
-                     Hp, Wp, top, left);
+  dim3 grid(zt_cdiv(Wp, 64), zt_cdiv(Hp, 4)), block(64, 4);
+  if (dt == 0) hipLaunchKernelGGL(raft_pack_kernel<float>, grid, block, 0, stream, img1, q2, lut, (float*)dst, ld, h, w, Hp, Wp, top, left);
+  else hipLaunchKernelGGL(raft_pack_kernel<zt_bf16>, grid, block, 0, stream, img1, q2, lut, (zt_bf16*)dst, ld, h, w, Hp, Wp, top, left);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
 
-extern "C" int zt_raft_pack_pair_f32(const float* img1, const float* img2, float* dst, int h, int w, int Hp, int Wp,
-                                     hipStream_t stream) {
-  ZT_REQUIRE(img1 && img2 && dst && Hp >= h && Wp >= w && Hp % 8 == 0 && Wp % 8 == 0 && Hp - h < 8 && Wp - w < 8);
-  hipLaunchKernelGGL(raft_pack_pair_kernel, dim3(zt_cdiv(Wp, 64), zt_cdiv(Hp, 4)), dim3(64, 4), 0, stream, img1, img2, dst, h, w,
-                     Hp, Wp, (Hp - h) / 2, (Wp - w) / 2);
+extern "C" int zt_raft_pack_pair(const float* img1, const float* img2, void* dst, int dt, int ld, int h, int w, int Hp, int Wp,
+                                 hipStream_t stream) {
+  ZT_REQUIRE(img1 && img2 && dst && Hp >= h && Wp >= w && Hp % 8 == 0 && Wp % 8 == 0 && Hp - h < 8 && Wp - w < 8 && ld >= 3);
+  dim3 grid(zt_cdiv(Wp, 64), zt_cdiv(Hp, 4)), block(64, 4);
+  if (dt == 0) hipLaunchKernelGGL(raft_pack_pair_kernel<float>, grid, block, 0, stream, img1, img2, (float*)dst, ld, h, w, Hp, Wp, (Hp - h) / 2, (Wp - w) / 2);
+  else hipLaunchKernelGGL(raft_pack_pair_kernel<zt_bf16>, grid, block, 0, stream, img1, img2, (zt_bf16*)dst, ld, h, w, Hp, Wp, (Hp - h) / 2, (Wp - w) / 2);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
@@ -336,8 +352,8 @@ extern "C" int zt_corr_pool_f32(const float* src, float* dst, int npx, int hin, 
   return ZT_OK;
 }
 
-extern "C" int zt_corr_lookup_f32(const float* l0, const float* l1, const float* l2, const float* l3, int h, int w, int ld0,
-                                  const float* coords, float* out, int ldo, int npx, hipStream_t stream) {
+extern "C" int zt_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, int h, int w, int ld0,
+                              const float* coords, void* out, int dt, int ldo, int npx, hipStream_t stream) {
   ZT_REQUIRE(l0 && l1 && l2 && l3 && coords && out && ldo >= 324);
   LookupArgs a;
   a.lvl[0] = l0; a.lvl[1] = l1; a.lvl[2] = l2; a.lvl[3] = l3;
@@ -349,25 +365,30 @@ extern "C" int zt_corr_lookup_f32(const float* l0, const float* l1, const float*
   }
   a.coords = coords; a.out = out; a.npx = npx; a.ldo = ldo;
   long long total = (long long)npx * 324;
-  hipLaunchKernelGGL(corr_lookup_kernel, dim3((unsigned)zt_cdivl(total, 256)), dim3(256), 0, stream, a);
+  if (dt == 0) hipLaunchKernelGGL(corr_lookup_kernel<float>, dim3((unsigned)zt_cdivl(total, 256)), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(corr_lookup_kernel<zt_bf16>, dim3((unsigned)zt_cdivl(total, 256)), dim3(256), 0, stream, a);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
 
-extern "C" int zt_gru_rh_f32(const float* zr, int ldzr, const float* hbuf, int ldh, float* rh, int ldrh, int C, int npx,
-                             hipStream_t stream) {
+extern "C" int zt_gru_rh(const void* zr, int dt, int ldzr, const void* hbuf, int ldh, void* rh, int ldrh, int C, int npx,
+                         hipStream_t stream) {
   ZT_REQUIRE(zr && hbuf && rh);
   long long total = (long long)npx * C;
-  hipLaunchKernelGGL(gru_rh_kernel, dim3((unsigned)zt_cdivl(total, 256)), dim3(256), 0, stream, zr, ldzr, hbuf, ldh, rh, ldrh, C, total);
+  dim3 grid((unsigned)zt_cdivl(total, 256));
+  if (dt == 0) hipLaunchKernelGGL(gru_rh_kernel<float>, grid, dim3(256), 0, stream, (const float*)zr, ldzr, (const float*)hbuf, ldh, (float*)rh, ldrh, C, total);
+  else hipLaunchKernelGGL(gru_rh_kernel<zt_bf16>, grid, dim3(256), 0, stream, (const zt_bf16*)zr, ldzr, (const zt_bf16*)hbuf, ldh, (zt_bf16*)rh, ldrh, C, total);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
 
-extern "C" int zt_gru_update_f32(const float* zr, int ldzr, const float* q, int ldq, float* hbuf, int ldh, int C, int npx,
-                                 hipStream_t stream) {
+extern "C" int zt_gru_update(const void* zr, int dt, int ldzr, const void* q, int ldq, void* hbuf, int ldh, int C, int npx,
+                             hipStream_t stream) {
   ZT_REQUIRE(zr && q && hbuf);
   long long total = (long long)npx * C;
-  hipLaunchKernelGGL(gru_update_kernel, dim3((unsigned)zt_cdivl(total, 256)), dim3(256), 0, stream, zr, ldzr, q, ldq, hbuf, ldh, C, total);
+  dim3 grid((unsigned)zt_cdivl(total, 256));
+  if (dt == 0) hipLaunchKernelGGL(gru_update_kernel<float>, grid, dim3(256), 0, stream, (const float*)zr, ldzr, (const float*)q, ldq, (float*)hbuf, ldh, C, total);
+  else hipLaunchKernelGGL(gru_update_kernel<zt_bf16>, grid, dim3(256), 0, stream, (const zt_bf16*)zr, ldzr, (const zt_bf16*)q, ldq, (zt_bf16*)hbuf, ldh, C, total);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
@@ -379,11 +400,12 @@ extern "C" int zt_raft_coords_init_f32(float* coords, int h, int w, hipStream_t 
   return ZT_OK;
 }
 
-extern "C" int zt_raft_flow_step_f32(float* coords1, const float* delta, int ldd, int h, int w, float* f4, int ldf4, float* fhx,
-                                     int ldfhx, hipStream_t stream) {
+extern "C" int zt_raft_flow_step(float* coords1, const float* delta, int ldd, int h, int w, float* f4, int ldf4, void* fhx,
+                                 int ldfhx, void* fin, int ldfin, int dt, hipStream_t stream) {
   ZT_REQUIRE(coords1 && f4);
-  hipLaunchKernelGGL(flow_step_kernel, dim3(zt_cdiv(h * w, 256)), dim3(256), 0, stream, coords1, delta, ldd, w, h * w, f4, ldf4,
-                     fhx, ldfhx);
+  dim3 grid(zt_cdiv(h * w, 256));
+  if (dt == 0) hipLaunchKernelGGL(flow_step_kernel<float>, grid, dim3(256), 0, stream, coords1, delta, ldd, w, h * w, f4, ldf4, (float*)fhx, ldfhx, (float*)fin, ldfin);
+  else hipLaunchKernelGGL(flow_step_kernel<zt_bf16>, grid, dim3(256), 0, stream, coords1, delta, ldd, w, h * w, f4, ldf4, (zt_bf16*)fhx, ldfhx, (zt_bf16*)fin, ldfin);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

@@ -143,7 +143,7 @@ class RAFT(_Holder):                                       # raft.py:23-48
         Hp, Wp = (h + 7) // 8 * 8, (w + 7) // 8 * 8
         x2 = torch.empty((2, Hp, Wp, 4), dtype=torch.float32, device=dev)
         from .lib import current_stream
-        ops.lib.call("zt_raft_pack_pair_f32", image1.detach().contiguous().float(), image2.detach().contiguous().float(), x2, h, w,
+        ops.lib.call("zt_raft_pack_pair", image1.detach().contiguous().float(), image2.detach().contiguous().float(), x2, 0, 4, h, w,
                      Hp, Wp, current_stream(dev))
         return plan.run(x2, iters=iters)
 
@@ -215,7 +215,7 @@ class _ZeroTIGBase(nn.Module):
             self.__dict__["_eng"] = Engine(self._ops, params, bufs, is_WB=getattr(self, "is_WB", False), device=dev,
                                            precision=self.precision)
             rw = {"raft." + k: v.data for k, v in self.raft.state_dict().items()}
-            self.__dict__["_raftplan"] = RaftPlan(self._ops, rw, dev)
+            self.__dict__["_raftplan"] = RaftPlan(self._ops, rw, dev, precision=self.precision)
             self.__dict__["_sig"] = sig
         return self._eng, self._raftplan
 

@@ -286,10 +286,11 @@ class Ops:
         self.lib.call("zt_equalize_prepare_u8", x255, q, hist, lut, C, h * w, self._s(x255))
         return q, hist, lut
 
-    def raft_pack_input(self, img1, q2, lut, h, w):
+    def raft_pack_input(self, img1, q2, lut, h, w, dtype=torch.float32):
         Hp, Wp = (h + 7) // 8 * 8, (w + 7) // 8 * 8
-        out = torch.empty((2, Hp, Wp, 4), dtype=torch.float32, device=img1.device)
-        self.lib.call("zt_raft_pack_input_f32", img1, q2, lut, out, h, w, Hp, Wp, self._s(img1))
+        ld = 8 if dtype == torch.bfloat16 else 4
+        out = torch.empty((2, Hp, Wp, ld), dtype=dtype, device=img1.device)
+        self.lib.call("zt_raft_pack_input", img1, q2, lut, out, _dt(out), ld, h, w, Hp, Wp, self._s(img1))
         return out
 
     def corr_pyramid(self, corr0, h, w):
@@ -308,55 +309,67 @@ class Ops:
         npx = h * w
         if out is None:
             out = torch.empty((1, h, w, 324), dtype=torch.float32, device=corr0.device)
-        self.lib.call("zt_corr_lookup_f32", corr0, levels[0], levels[1], levels[2], h, w, corr0.shape[-1], coords, out,
+        self.lib.call("zt_corr_lookup", corr0, levels[0], levels[1], levels[2], h, w, corr0.shape[-1], coords, out, _dt(out),
                       out.shape[-1], npx, self._s(corr0))
         return out
 
     # ---- bf16 throughput mode of the convolution family ---------------------------------------------------------
-    def repack_weight_bf16(self, w, transpose_flip=False, out=None):
+    def repack_weight_bf16(self, w, transpose_flip=False, out=None, co_off=0):
         """torch fp32 [Cout,Cin,KH,KW] -> bf16 [KH*KW, CoutP16, ldk8] (input channel fastest); zero padded."""
         _f32c(w)
         Cout, Cin, KH, KW = w.shape
         n_out, n_in = (Cin, Cout) if transpose_flip else (Cout, Cin)
-        CoutP, ldk = (n_out + 15) // 16 * 16, (n_in + 7) // 8 * 8
         if out is None:
+            CoutP, ldk = (n_out + 15) // 16 * 16, (n_in + 7) // 8 * 8
             out = torch.zeros((KH * KW, CoutP, ldk), dtype=torch.bfloat16, device=w.device)
-        self.lib.call("zt_repack_conv_weight_bf16", w, out, Cout, Cin, KH, KW, CoutP, ldk, int(transpose_flip), self._s(w))
+        CoutP, ldk = out.shape[1], out.shape[2]
+        self.lib.call("zt_repack_conv_weight_bf16", w, out, Cout, Cin, KH, KW, CoutP, ldk, co_off, int(transpose_flip), self._s(w))
         return out
 
-    def conv2d_bf16(self, x, wdev, bias, Cout, KH, KW, pad=(0, 0), act=None, alpha=1.0, out=None, out_planar=False, aux=None, epi=0):
-        """x: CV over a bf16 NHWC buffer.  out: bf16 NHWC (CV/tensor) or fp32 planar [N,Cout,Ho,Wo] when out_planar."""
+    def conv2d_bf16(self, x, wdev, bias, Cout, KH, KW, pad=(0, 0), act=None, alpha=1.0, out=None, out_planar=False, aux=None, epi=0,
+                    stride=1, x2=None, out_f32=False, w_roff=0):
+        """x (and optional x2 for channels >= x.C): CV over bf16 NHWC buffers.  out: bf16 NHWC (default), fp32 NHWC (out_f32)
+        or fp32 planar [N,Cout,Ho,Wo] (out_planar).  w_roff: first output-channel row of wdev to use."""
         x = _cv(x)
         assert x.t.dtype == torch.bfloat16 and wdev.dtype == torch.bfloat16 and wdev.shape[0] == KH * KW
-        CoutP, ldk = wdev.shape[1], wdev.shape[2]
-        assert ldk >= x.C and CoutP >= Cout
-        Ho, Wo = x.H + 2 * pad[0] - KH + 1, x.W + 2 * pad[1] - KW + 1
+        Cin, csplit, ldx2, x2p = x.C, 0, 0, None
+        if x2 is not None:
+            x2 = _cv(x2)
+            assert x2.t.dtype == torch.bfloat16
+            csplit, Cin, ldx2, x2p = x.C, x.C + x2.C, x2.ld, x2.ptr
+        CoutP, ldk = wdev.shape[1] - w_roff, wdev.shape[2]
+        assert ldk >= Cin and CoutP >= Cout and (KH * KW == 1 or w_roff == 0)
+        Ho = (x.H + 2 * pad[0] - KH) // stride + 1
+        Wo = (x.W + 2 * pad[1] - KW) // stride + 1
         dev = x.t.device
         if out_planar:
             if out is None:
                 out = torch.empty((x.N, Cout, Ho, Wo), dtype=torch.float32, device=dev)
-            yptr, ldy = out.data_ptr(), out.stride(1)
+            yptr, ldy, mode = out.data_ptr(), out.stride(1), 1
         else:
+            odt = torch.float32 if out_f32 else torch.bfloat16
+            gran = 4 if out_f32 else 8
             if out is None:
-                ld = (Cout + 7) // 8 * 8
-                out = torch.empty((x.N, Ho, Wo, ld), dtype=torch.bfloat16, device=dev)
+                ld = (Cout + gran - 1) // gran * gran
+                out = torch.empty((x.N, Ho, Wo, ld), dtype=odt, device=dev)
                 if ld != Cout:
                     out.zero_()
             o = _cv(out)
-            assert o.t.dtype == torch.bfloat16 and (o.N, o.H, o.W) == (x.N, Ho, Wo) and o.C >= Cout
-            yptr, ldy = o.ptr, o.ld
+            assert o.t.dtype == odt and (o.N, o.H, o.W) == (x.N, Ho, Wo) and o.C >= Cout
+            yptr, ldy, mode = o.ptr, o.ld, (2 if out_f32 else 0)
         auxp, ldaux = None, 0
         if epi:
             av = _cv(aux)
             assert av.t.dtype == torch.bfloat16
             auxp, ldaux = av.ptr, av.ld
         prof = getattr(self, "profile", None)
-        timed = prof is not None and prof["match"] == (KH, KW, 1, x.C, Cout, x.H, x.W)
+        timed = prof is not None and prof["match"] == (KH, KW, stride, Cin, Cout, x.H, x.W)
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        self.lib.call("zt_conv2d_nhwc_bf16", x.ptr, x.ld, x.N, x.H, x.W, x.C, wdev, CoutP, ldk, bias, yptr, ldy, int(out_planar),
-                      Cout, KH, KW, 1, pad[0], pad[1], ACT[act], float(alpha), auxp, ldaux, epi, self._s(x.t))
+        self.lib.call("zt_conv2d_nhwc_bf16", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin, wdev.data_ptr() + 2 * w_roff * ldk,
+                      CoutP, ldk, bias, yptr, ldy, mode, Cout, KH, KW, stride, pad[0], pad[1], ACT[act], float(alpha), auxp, ldaux,
+                      epi, self._s(x.t))
         if timed:
             e1.record()
             prof["events"].append((e0, e1))

@@ -1,7 +1,10 @@
 """Frozen RAFT-basic (reference model/RAFT/{raft,extractor,update,corr}.py) as a static inference plan over the HIP
 kernels: instance-norm feature encoder on both frames, eval-BN context encoder, all-pairs correlation volume as an MFMA
 1x1 convolution, pyramid, 12 refinement iterations (fused 4-level lookup, motion encoder, SepConvGRU, flow head) and
-the convex 8x up-sampling of the last iteration only (the reference computes it 12 times and keeps the last)."""
+the convex 8x up-sampling of the last iteration only (the reference computes it 12 times and keeps the last).
+
+precision "fp32": exact-fp32 MFMA everywhere (parity mode).  "bf16": feature maps / GRU state / weights bf16 in HBM with fp32
+accumulation; the correlation volume, flow bookkeeping, up-sampling mask and everything downstream (warp) stay fp32."""
 import torch
 
 from .lib import current_stream
@@ -9,10 +12,13 @@ from .ops import CV
 
 
 class RaftPlan:
-    def __init__(self, ops, weights, device, prefix="raft"):
+    def __init__(self, ops, weights, device, prefix="raft", precision="fp32"):
         """weights: {name: tensor on device} with the reference's `raft.*` state-dict names."""
         self.ops, self.lib, self.dev, self.pre = ops, ops.lib, device, prefix
-        self.W = weights
+        self.W = dict(weights)
+        self.h = precision == "bf16"
+        self.adt = torch.bfloat16 if self.h else torch.float32
+        self.dt = 1 if self.h else 0
         self.wd, self.bn = {}, {}
         self._prepare()
 
@@ -21,24 +27,30 @@ class RaftPlan:
 
     def _prepare(self):
         o = self.ops
-        for k, v in self.W.items():
+        rp = o.repack_weight_bf16 if self.h else o.repack_weight
+        for k, v in list(self.W.items()):
             if not k.startswith(self.pre + ".") or not k.endswith(".weight") or v.dim() != 4:
                 continue
             name = k[len(self.pre) + 1:-7]
             if ".gru.conv" in name:
                 continue
-            self.wd[name] = o.repack_weight(v.contiguous())
+            self.wd[name] = rp(v.contiguous())
         g = "update_block.gru."
         for sfx in ("1", "2"):
             wz, wr = self._w(g + "convz" + sfx + ".weight"), self._w(g + "convr" + sfx + ".weight")
             kh, kw = wz.shape[2], wz.shape[3]
-            buf = torch.zeros((kh * kw, 384, 256), dtype=torch.float32, device=self.dev)
-            o.repack_weight(wz.contiguous(), ldw=256, co_off=0, out=buf)
-            o.repack_weight(wr.contiguous(), ldw=256, co_off=128, out=buf)
+            if self.h:
+                buf = torch.zeros((kh * kw, 256, 384), dtype=torch.bfloat16, device=self.dev)
+                o.repack_weight_bf16(wz.contiguous(), out=buf, co_off=0)
+                o.repack_weight_bf16(wr.contiguous(), out=buf, co_off=128)
+            else:
+                buf = torch.zeros((kh * kw, 384, 256), dtype=torch.float32, device=self.dev)
+                o.repack_weight(wz.contiguous(), ldw=256, co_off=0, out=buf)
+                o.repack_weight(wr.contiguous(), ldw=256, co_off=128, out=buf)
             self.wd[g + "convzr" + sfx] = buf
             self.W[self.pre + "." + g + "convzr" + sfx + ".bias"] = torch.cat(
                 [self._w(g + "convz" + sfx + ".bias"), self._w(g + "convr" + sfx + ".bias")]).contiguous()
-            self.wd[g + "convq" + sfx] = o.repack_weight(self._w(g + "convq" + sfx + ".weight").contiguous())
+            self.wd[g + "convq" + sfx] = rp(self._w(g + "convq" + sfx + ".weight").contiguous())
         # eval-mode BatchNorm of the context encoder folded to scale / shift once (running stats are frozen)
         for k in list(self.W.keys()):
             if k.startswith(self.pre + ".cnet") and k.endswith(".running_mean") and ".downsample.1." not in k:
@@ -48,7 +60,19 @@ class RaftPlan:
                                                self._w(name + ".running_mean"), self._w(name + ".running_var"), dev=self.dev)
                 self.bn[name] = (sc, sh)
 
-    # ------------------------------------------------------------------------------------------------ encoders
+    # ------------------------------------------------------------------------------------------------ building blocks
+    def _conv(self, x, name, cout, k, stride=1, pad=None, act=None, alpha=1.0, out=None, x2=None, out_f32=False, bias=True, row0=0):
+        """Convolution in the plan's precision.  row0: first output channel of the packed weight to use (1x1 only)."""
+        kh, kw = (k, k) if isinstance(k, int) else k
+        pad = (kh // 2, kw // 2) if pad is None else pad
+        b = self._w(name + ".bias") if bias else None
+        if b is not None and row0:
+            b = b[row0:]
+        if self.h:
+            return self.ops.conv2d_bf16(x, self.wd[name], b, cout, kh, kw, pad, act, alpha=alpha, out=out, stride=stride, x2=x2,
+                                        out_f32=out_f32, w_roff=row0)
+        return self.ops.conv2d(x, self.wd[name], b, cout, kh, kw, stride, pad, act, alpha=alpha, out=out, x2=x2, w_coff=row0)
+
     def _norm(self, y, name, kind, inner_relu, res=None, outer_relu=False):
         o = self.ops
         if kind == "instance":
@@ -58,11 +82,6 @@ class RaftPlan:
         else:
             sc, sh = self.bn[name]
         return o.norm_apply(y, sc, sh, res=res, inner_relu=inner_relu, outer_relu=outer_relu)
-
-    def _conv(self, x, name, cout, k, stride=1, pad=None, act=None, **kw):
-        kh, kw_ = (k, k) if isinstance(k, int) else k
-        pad = (kh // 2, kw_ // 2) if pad is None else pad
-        return self.ops.conv2d(x, self.wd[name], self._w(name + ".bias"), cout, kh, kw_, stride, pad, act, **kw)
 
     def _res_block(self, p, x, dim, stride, kind):
         y = self._conv(x, p + ".conv1", dim, 3, stride)
@@ -84,58 +103,70 @@ class RaftPlan:
             y = self._res_block("%s.layer%d.1" % (enc, li), y, dim, 1, kind)
         return y
 
+    def _new(self, *shape, dtype=None, zero=False):
+        f = torch.zeros if zero else torch.empty
+        return f(shape, dtype=self.adt if dtype is None else dtype, device=self.dev)
+
     # ------------------------------------------------------------------------------------------------ full inference
     def run(self, x2, iters=12, want_aux=False):
-        """x2: NHWC [2,Hp,Wp,4] (both padded, normalised frames).  Returns (flow_low [1,2,h8,w8], flow_up [1,2,Hp,Wp])."""
-        o, lib, dev = self.ops, self.lib, self.dev
+        """x2: NHWC [2,Hp,Wp,ld] (both padded, normalised frames) in the plan's storage type.
+        Returns (flow_low [1,2,h8,w8], flow_up [1,2,Hp,Wp]) fp32."""
+        o, lib, dev, dt = self.ops, self.lib, self.dev, self.dt
         s = current_stream(dev)
         _, Hp, Wp, _ = x2.shape
         h, w = Hp // 8, Wp // 8
         npx = h * w
         # feature encoder (both frames), correlation volume + pyramid
         f = self._encoder("fnet", x2, "instance")
-        fmap1 = o.conv2d(CV(f[0:1]), self.wd["fnet.conv2"], self._w("fnet.conv2.bias"), 256, 1, 1)
-        pitch = (npx + 15) // 16 * 16
-        fmap2 = torch.zeros((1, 256, pitch), dtype=torch.float32, device=dev)
-        o.conv2d(CV(f[1:2]), self.wd["fnet.conv2"], self._w("fnet.conv2.bias"), 256, 1, 1, out=fmap2, out_planar=True)
-        corr0 = o.conv2d(CV(fmap1), fmap2, None, npx, 1, 1, alpha=1.0 / 16.0)      # corr.py:52-60: / sqrt(256)
+        fmap1 = self._conv(CV(f[0:1]), "fnet.conv2", 256, 1)
+        if self.h:
+            npxp = (npx + 15) // 16 * 16
+            fmap2 = self._new(npxp, 256, zero=True)                         # nhwc == the bf16 weight layout [CoutP][ldk]
+            self._conv(CV(f[1:2]), "fnet.conv2", 256, 1, out=fmap2[:npx].view(1, h, w, 256))
+            corr0 = o.conv2d_bf16(CV(fmap1), fmap2.view(1, npxp, 256), None, npx, 1, 1, alpha=1.0 / 16.0, out_f32=True)
+        else:
+            pitch = (npx + 15) // 16 * 16
+            fmap2 = self._new(1, 256, pitch, zero=True)
+            o.conv2d(CV(f[1:2]), self.wd["fnet.conv2"], self._w("fnet.conv2.bias"), 256, 1, 1, out=fmap2, out_planar=True)
+            corr0 = o.conv2d(CV(fmap1), fmap2, None, npx, 1, 1, alpha=1.0 / 16.0)      # corr.py:52-60: / sqrt(256)
         levels = o.corr_pyramid(corr0, h, w)
         # context encoder -> hidden state (tanh) and context (relu) straight into the GRU input buffer
         c = self._encoder("cnet", x2[0:1], "batch")
-        HX = torch.zeros((1, h, w, 384), dtype=torch.float32, device=dev)     # [net | inp | motion(126) | flow(2)]
-        bias = self._w("cnet.conv2.bias")
-        o.conv2d(CV(c), self.wd["cnet.conv2"], bias, 128, 1, 1, act="tanh", out=CV(HX, 0, 128))
-        o.conv2d(CV(c), self.wd["cnet.conv2"], bias[128:], 128, 1, 1, act="relu", out=CV(HX, 128, 128), w_coff=128)
-        coords1 = torch.empty((npx, 2), dtype=torch.float32, device=dev)
+        HX = self._new(1, h, w, 384, zero=True)                              # [net | inp | motion(126) | flow(2)]
+        self._conv(CV(c), "cnet.conv2", 128, 1, act="tanh", out=CV(HX, 0, 128))
+        self._conv(CV(c), "cnet.conv2", 128, 1, act="relu", out=CV(HX, 128, 128), row0=128)
+        coords1 = self._new(npx, 2, dtype=torch.float32)
         lib.call("zt_raft_coords_init_f32", coords1, h, w, s)
-        F4 = torch.zeros((1, h, w, 4), dtype=torch.float32, device=dev)
-        lib.call("zt_raft_flow_step_f32", coords1, None, 0, h, w, F4, 4, HX.data_ptr() + 4 * 382, 384, s)
-        CF = torch.empty((1, h, w, 256), dtype=torch.float32, device=dev)
-        RH = torch.empty((1, h, w, 128), dtype=torch.float32, device=dev)
-        CORR = torch.empty((1, h, w, 324), dtype=torch.float32, device=dev)
+        F4 = self._new(1, h, w, 4, dtype=torch.float32, zero=True)           # fp32 flow for the up-sampler
+        ldfin = 8 if self.h else 4
+        FIN = self._new(1, h, w, ldfin, zero=True)                           # flow as the 7x7 conv input
+        es = HX.element_size()
+        lib.call("zt_raft_flow_step", coords1, None, 0, h, w, F4, 4, HX.data_ptr() + es * 382, 384, FIN, ldfin, dt, s)
+        CF, RH = self._new(1, h, w, 256), self._new(1, h, w, 128)
+        CORR = self._new(1, h, w, 328 if self.h else 324, zero=True)
         e, g = "update_block.encoder.", "update_block.gru."
         aux = {}
         for it in range(iters):
             o.corr_lookup(corr0, levels, h, w, coords1, out=CORR)
             if want_aux and it == 0:
                 aux["corr0"] = CORR.clone()
-            cor1 = self._conv(CORR, e + "convc1", 256, 1, act="relu")
+            cor1 = self._conv(CV(CORR, 0, 324), e + "convc1", 256, 1, act="relu")
             self._conv(cor1, e + "convc2", 192, 3, act="relu", out=CV(CF, 0, 192))
-            flo1 = self._conv(CV(F4, 0, 2), e + "convf1", 128, 7, act="relu")
+            flo1 = self._conv(CV(FIN, 0, 2), e + "convf1", 128, 7, act="relu")
             self._conv(flo1, e + "convf2", 64, 3, act="relu", out=CV(CF, 192, 64))
             self._conv(CF, e + "conv", 126, 3, act="relu", out=CV(HX, 256, 126))
             for sfx, k, pad in (("1", (1, 5), (0, 2)), ("2", (5, 1), (2, 0))):
                 zr = self._conv(HX, g + "convzr" + sfx, 256, k, pad=pad, act="sigmoid")
-                lib.call("zt_gru_rh_f32", zr, 256, HX, 384, RH, 128, 128, npx, s)
+                lib.call("zt_gru_rh", zr, dt, 256, HX, 384, RH, 128, 128, npx, s)
                 q = self._conv(CV(RH), g + "convq" + sfx, 128, k, pad=pad, act="tanh", x2=CV(HX, 128, 256))
-                lib.call("zt_gru_update_f32", zr, 256, q, 128, HX, 384, 128, npx, s)
+                lib.call("zt_gru_update", zr, dt, 256, q, 128, HX, 384, 128, npx, s)
             fh = self._conv(CV(HX, 0, 128), "update_block.flow_head.conv1", 256, 3, act="relu")
-            delta = self._conv(fh, "update_block.flow_head.conv2", 2, 3)
-            lib.call("zt_raft_flow_step_f32", coords1, delta, delta.shape[-1], h, w, F4, 4, HX.data_ptr() + 4 * 382, 384, s)
+            delta = self._conv(fh, "update_block.flow_head.conv2", 2, 3, out_f32=True)       # fp32 [..,4]
+            lib.call("zt_raft_flow_step", coords1, delta, delta.shape[-1], h, w, F4, 4, HX.data_ptr() + es * 382, 384, FIN, ldfin, dt, s)
         m1 = self._conv(CV(HX, 0, 128), "update_block.mask.0", 256, 3, act="relu")
-        mask = self._conv(m1, "update_block.mask.2", 576, 1, alpha=0.25)
-        flow_up = torch.empty((1, 2, Hp, Wp), dtype=torch.float32, device=dev)
-        flow_low = torch.empty((1, 2, h, w), dtype=torch.float32, device=dev)
+        mask = self._conv(m1, "update_block.mask.2", 576, 1, alpha=0.25, out_f32=True)
+        flow_up = self._new(1, 2, Hp, Wp, dtype=torch.float32)
+        flow_low = self._new(1, 2, h, w, dtype=torch.float32)
         lib.call("zt_convex_upsample_f32", F4, 4, mask, 576, flow_up, flow_low, h, w, s)
         if want_aux:
             aux.update(fmap1=fmap1, fmap2=fmap2, HX=HX, mask=mask)
@@ -150,7 +181,7 @@ class RaftPlan:
         a = o.resize_bilinear(last_H3.contiguous(), ht, wd, 255.0)
         b = o.resize_bilinear(L2, ht, wd, 255.0)
         q, _, lut = o.equalize_prepare(b)
-        x2 = o.raft_pack_input(a, q, lut, ht, wd)
+        x2 = o.raft_pack_input(a, q, lut, ht, wd, dtype=self.adt)
         flow_low, flow_up = self.run(x2)
         wpH, wps = o.warp2(flow_up, last_H3.contiguous(), last_s3.contiguous())
         if want_aux:
