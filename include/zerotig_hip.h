@@ -189,6 +189,10 @@ int zt_probe_mfma_bf16(const unsigned short* A, const unsigned short* B, float* 
 int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin, const void* w,
                         int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout, int KH, int KW, int stride,
                         int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi, zt_stream_t stream);
+/* same, with the kernel variant pinned (tests / tuning): 0 auto, 1 persistent weight-stationary (stride 1, K in {1,3}, Cin <= 64, N == 1), 2 tiled */
+int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin, const void* w,
+                                int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout, int KH, int KW, int stride,
+                                int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi, int variant, zt_stream_t stream);
 int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout, int KH, int KW,
                               float* slab, size_t slab_bytes, float* grad_w, int accumulate, zt_stream_t stream);
 int zt_repack_conv_weight_bf16(const float* src, void* dst, int Cout, int Cin, int KH, int KW, int CoutP, int ldk, int co_off,

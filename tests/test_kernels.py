@@ -331,15 +331,16 @@ BF16_CONV = [(3, 48, 3, 8, "lrelu"), (48, 48, 3, 48, "lrelu"), (64, 64, 3, 64, "
              (48, 6, 1, 48, None), (9, 64, 3, 16, "relu"), (12, 48, 3, 16, None)]
 
 
+@pytest.mark.parametrize("variant", [2, 1], ids=["tiled", "ws"])
 @pytest.mark.parametrize("case", BF16_CONV, ids=lambda c: "c%d-%d_k%d" % c[:3])
-def test_conv_bf16(backend, case):
+def test_conv_bf16(backend, case, variant):
     import torch.nn.functional as F
     from importlib import import_module
     CV = import_module("zero-tig_amd.ops").CV
     ops, dev, _ = backend
     Cin, Cout, K, ld, act = case
     g = torch.Generator().manual_seed(Cin * 17 + Cout)
-    H, W = 7, 37
+    H, W = (19, 37) if variant == 1 else (7, 37)          # 19 rows: three 8-row tiles of the persistent kernel, ragged
     x = torch.randn(1, Cin, H, W, generator=g).bfloat16().float()
     w = (torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5)
     b = torch.randn(Cout, generator=g) * 0.1
@@ -348,11 +349,11 @@ def test_conv_bf16(backend, case):
            "sigmoid_clamp": lambda t: torch.clamp(torch.sigmoid(t), 1e-4, 1)}[act](ref)
     xd = _nhwc_bf16(x, ld).to(dev)
     wd = ops.repack_weight_bf16(w.to(dev))
-    y = ops.conv2d_bf16(CV(xd, 0, Cin), wd, b.to(dev), Cout, K, K, (K // 2, K // 2), act)
+    y = ops.conv2d_bf16(CV(xd, 0, Cin), wd, b.to(dev), Cout, K, K, (K // 2, K // 2), act, variant=variant)
     got = y.float().cpu()[..., :Cout].permute(0, 3, 1, 2)
     assert float(((got - ref).abs() - ref.abs() * 2 ** -8).max()) < 2e-3
     if Cout <= 6:
-        yp = ops.conv2d_bf16(CV(xd, 0, Cin), wd, b.to(dev), Cout, K, K, (K // 2, K // 2), act, out_planar=True)
+        yp = ops.conv2d_bf16(CV(xd, 0, Cin), wd, b.to(dev), Cout, K, K, (K // 2, K // 2), act, out_planar=True, variant=variant)
         assert maxerr(yp, ref) < 2e-4            # fp32 planar output: only the bf16 inputs differ from the fp32 reference
     # dgrad operator with the LeakyReLU-mask epilogue
     if Cin >= 48 and Cout >= 48:
@@ -363,7 +364,7 @@ def test_conv_bf16(backend, case):
         refg = xg.grad * torch.where(aux > 0, 1.0, 0.2)
         wt = ops.repack_weight_bf16(w.to(dev), transpose_flip=True)
         dx = ops.conv2d_bf16(CV(_nhwc_bf16(dz, Cout).to(dev)), wt, None, Cin, K, K, (K // 2, K // 2), None,
-                             aux=_nhwc_bf16(aux, Cin).to(dev), epi=1)
+                             aux=_nhwc_bf16(aux, Cin).to(dev), epi=1, variant=variant)
         gotg = dx.float().cpu().permute(0, 3, 1, 2)
         assert float(((gotg - refg).abs() - refg.abs() * 2 ** -8).max()) < 2e-3
 

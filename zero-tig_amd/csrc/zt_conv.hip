@@ -502,6 +502,155 @@ int launch_conv_h(const ConvArgsH& a, int NT, unsigned gx, hipStream_t stream) {
   return 0;
 }
 
+// ---- persistent, weight-stationary variant for the full-resolution enhancement / denoising layers (stride 1, K in {1,3},
+// Cin <= 64): each workgroup (8 waves = 8 output rows x 32 columns) loads ALL its weights into LDS once and then walks
+// pixel tiles grid-stride; the next tile's halo is prefetched into registers while the MFMAs of the current one run
+// (two barriers per tile).  LDS rows are [pixel | cout][CCH*32 + 8] bf16 (144 B or 80 B pitch: conflict-free b128 reads).
+constexpr int PTH = 8;
+
+template <int K, int NT, int CCH>
+__global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntiles) {
+  constexpr int CP = CCH * 32 + 8;
+  constexpr int IR = PTH + K - 1, IC = TW + K - 1;
+  constexpr int NPF = (IR * IC * CCH * 4 + 511) / 512;           // 16-byte prefetch registers per thread
+  __shared__ __attribute__((aligned(16))) zt_bf16 ws[K * K * NT * 16 * CP];
+  __shared__ __attribute__((aligned(16))) zt_bf16 xs[IR * IC * CP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int co0 = blockIdx.y * (NT * 16);
+  constexpr int pad = (K - 1) / 2;
+
+  for (int e = tid; e < K * K * NT * 16 * CCH * 4; e += 512) {
+    int q = e % (CCH * 4);
+    int r = e / (CCH * 4);
+    int co = r % (NT * 16), tap = r / (NT * 16);
+    int c = q * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (c < a.ldk && co0 + co < a.CoutP) v = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.CoutP + co0 + co) * a.ldk + c);
+    *reinterpret_cast<uint4*>(ws + (tap * NT * 16 + co) * CP + c) = v;
+  }
+
+  uint4 pf[NPF];
+  auto prefetch = [&](int tile) {
+    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const int gy0 = ty * PTH - pad, gx0 = tx * TW - pad;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      int e = tid + i * 512;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (e < IR * IC * CCH * 4) {
+        int q = e % (CCH * 4), p = e / (CCH * 4);
+        int iy = p / IC, ixx = p - iy * IC;
+        int gy = gy0 + iy, gx = gx0 + ixx;
+        int c = q * 8;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Cin) {
+          v = *reinterpret_cast<const uint4*>(a.x + ((size_t)gy * a.W + gx) * a.ldx + c);
+          if (c + 8 > a.Cin) {
+            zt_bf16 tmp[8];
+            __builtin_memcpy(tmp, &v, 16);
+            for (int j = 0; j < 8; ++j)
+              if (c + j >= a.Cin) tmp[j] = 0;
+            __builtin_memcpy(&v, tmp, 16);
+          }
+        }
+      }
+      pf[i] = v;
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) prefetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      int e = tid + i * 512;
+      if (e < IR * IC * CCH * 4) *reinterpret_cast<uint4*>(xs + (e / (CCH * 4)) * CP + (e % (CCH * 4)) * 8) = pf[i];
+    }
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < ntiles) prefetch(next);
+
+    zt_f32x4 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q = 0; q < NT; ++q) acc[m][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < K * K; ++tap) {
+      const int ky = tap / K, kx = tap % K;
+#pragma unroll
+      for (int kc = 0; kc < CCH; ++kc) {
+        zt_s16x8 av[2], bv[NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          av[m] = *reinterpret_cast<const zt_s16x8*>(xs + ((wave + ky) * IC + m * 16 + l15 + kx) * CP + kc * 32 + 8 * l4);
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+          bv[q] = *reinterpret_cast<const zt_s16x8*>(ws + (tap * NT * 16 + q * 16 + l15) * CP + kc * 32 + 8 * l4);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(av[m], bv[q], acc[m][q]);
+      }
+    }
+
+    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const int oy = ty * PTH + wave, ox0 = tx * TW;
+    if (oy < a.Ho) {
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        const int co = co0 + q * 16 + l15;
+        if (co < a.Cout) {
+          const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ox = ox0 + m * 16 + l4 * 4 + j;
+              if (ox < a.Wo) {
+                float v = apply_act(a.alpha * (acc[m][q][j] + b), a.act);
+                const size_t pix = (size_t)oy * a.Wo + ox;
+                if (a.epi) {
+                  float u = zt_bf2f(a.aux[pix * a.ldaux + co]);
+                  if (a.epi == 1) v *= (u > 0.f ? 1.f : 0.2f);
+                  else if (a.epi == 2) v *= (u > 0.f ? 1.f : 0.f);
+                  else v += u;
+                }
+                if (a.out_mode == 1) ((float*)a.y)[(size_t)co * a.ldy + pix] = v;
+                else if (a.out_mode == 2) ((float*)a.y)[pix * a.ldy + co] = v;
+                else ((zt_bf16*)a.y)[pix * a.ldy + co] = zt_f2bf(v);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int K>
+int launch_conv_ws(const ConvArgsH& a, int NT, int CCH, hipStream_t stream) {
+  int c16 = (a.Cout + 15) / 16;
+  int ntiles = a.tilesX * a.tilesY;
+  int per_cu = (CCH == 1 && NT <= 3) ? 2 : 1;
+  int gx = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+  dim3 grid(gx, (c16 + NT - 1) / NT), block(512);
+#define ZT_WS(nt, cch) hipLaunchKernelGGL((conv_ws_bf16_kernel<K, nt, cch>), grid, block, 0, stream, a, ntiles); return 0
+  if (CCH == 1) {
+    if (NT == 1) { ZT_WS(1, 1); }
+    if (NT == 2) { ZT_WS(2, 1); }
+    if (NT == 3) { ZT_WS(3, 1); }
+    ZT_WS(4, 1);
+  }
+  if (NT == 1) { ZT_WS(1, 2); }
+  if (NT == 2) { ZT_WS(2, 2); }
+  if (NT == 3) { ZT_WS(3, 2); }
+  ZT_WS(4, 2);
+#undef ZT_WS
+}
+
 // ---- bf16 weight gradient.  K = pixels: the MFMA needs 8 consecutive PIXELS per lane for one channel, i.e. the
 // transpose of the NHWC tile; ds_read_b64_tr_b16 delivers exactly that from a [pixel][channel] LDS image, so staging is a
 // plain 16-byte copy and tap shifts are row shifts (alignment preserved).
@@ -734,10 +883,11 @@ extern "C" int zt_repack_conv_weight_f32(const float* src, float* dst, int Cout,
   return ZT_OK;
 }
 
-extern "C" int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
-                                   const void* w, int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout,
-                                   int KH, int KW, int stride, int padH, int padW, int act, float alpha, const void* aux,
-                                   int ldaux, int epi, hipStream_t stream) {
+// variant: 0 = choose by problem size, 1 = force the persistent weight-stationary kernel, 2 = force the tiled kernel
+extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
+                                           const void* w, int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode,
+                                           int Cout, int KH, int KW, int stride, int padH, int padW, int act, float alpha,
+                                           const void* aux, int ldaux, int epi, int variant, hipStream_t stream) {
   ZT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && out_mode >= 0 && out_mode <= 2);
   ZT_REQUIRE(ldx % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
   ZT_REQUIRE(!x2 || (csplit % HCK == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0));
@@ -758,6 +908,18 @@ extern "C" int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, in
   long long wgs = (long long)zt_cdiv(a.Wo, 32) * a.tilesY * N * zt_cdiv(c16, NT);
   if (wgs < 512 || stride == 2) MT = 1;
   if (MT == 1 && NT == 4 && (long long)zt_cdiv(a.Wo, 16) * a.tilesY * N * zt_cdiv(c16, NT) < 512 && c16 % 2 == 0) NT = 2;
+  // full-resolution stride-1 layers of the enhancement nets: persistent weight-stationary kernel
+  const bool ws_ok = N == 1 && stride == 1 && KH == KW && (KH == 1 || KH == 3) && padH == KH / 2 && padW == KW / 2 && Cin <= 64 && !x2;
+  ZT_REQUIRE(variant != 1 || ws_ok);
+  if (variant != 2 && ws_ok && (variant == 1 || (long long)zt_cdiv(a.Wo, TW) * zt_cdiv(a.Ho, PTH) >= 1024)) {
+    a.tilesX = zt_cdiv(a.Wo, TW);
+    a.tilesY = zt_cdiv(a.Ho, PTH);
+    int CCH = Cin <= 32 ? 1 : 2;
+    int rcw = (KH == 3) ? launch_conv_ws<3>(a, NT, CCH, stream) : launch_conv_ws<1>(a, NT, CCH, stream);
+    if (rcw) return rcw;
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+  }
   a.tilesX = zt_cdiv(a.Wo, 16 * MT);
   unsigned gx = (unsigned)(a.tilesX * a.tilesY * N);
   int rc = ZT_EINVAL;
@@ -769,6 +931,14 @@ extern "C" int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, in
   if (rc) return rc;
   ZT_LAUNCH_CHECK();
   return ZT_OK;
+}
+
+extern "C" int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
+                                   const void* w, int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout,
+                                   int KH, int KW, int stride, int padH, int padW, int act, float alpha, const void* aux,
+                                   int ldaux, int epi, hipStream_t stream) {
+  return zt_conv2d_nhwc_bf16_variant(x, x2, csplit, ldx, ldx2, N, H, W, Cin, w, CoutP, ldk, bias, y, ldy, out_mode, Cout, KH, KW,
+                                     stride, padH, padW, act, alpha, aux, ldaux, epi, 0, stream);
 }
 
 extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout,

@@ -327,7 +327,7 @@ class Ops:
         return out
 
     def conv2d_bf16(self, x, wdev, bias, Cout, KH, KW, pad=(0, 0), act=None, alpha=1.0, out=None, out_planar=False, aux=None, epi=0,
-                    stride=1, x2=None, out_f32=False, w_roff=0):
+                    stride=1, x2=None, out_f32=False, w_roff=0, variant=0):
         """x (and optional x2 for channels >= x.C): CV over bf16 NHWC buffers.  out: bf16 NHWC (default), fp32 NHWC (out_f32)
         or fp32 planar [N,Cout,Ho,Wo] (out_planar).  w_roff: first output-channel row of wdev to use."""
         x = _cv(x)
@@ -367,9 +367,9 @@ class Ops:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        self.lib.call("zt_conv2d_nhwc_bf16", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin, wdev.data_ptr() + 2 * w_roff * ldk,
-                      CoutP, ldk, bias, yptr, ldy, mode, Cout, KH, KW, stride, pad[0], pad[1], ACT[act], float(alpha), auxp, ldaux,
-                      epi, self._s(x.t))
+        self.lib.call("zt_conv2d_nhwc_bf16_variant", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin,
+                      wdev.data_ptr() + 2 * w_roff * ldk, CoutP, ldk, bias, yptr, ldy, mode, Cout, KH, KW, stride, pad[0], pad[1],
+                      ACT[act], float(alpha), auxp, ldaux, epi, variant, self._s(x.t))
         if timed:
             e1.record()
             prof["events"].append((e0, e1))
