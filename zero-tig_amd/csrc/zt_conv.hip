@@ -513,8 +513,9 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
   constexpr int CP = CCH * 32 + 8;
   constexpr int IR = PTH + K - 1, IC = TW + K - 1;
   constexpr int NPF = (IR * IC * CCH * 4 + 511) / 512;           // 16-byte prefetch registers per thread
+  constexpr int XS_HALO = IR * IC * CP, XS_STAGE = PTH * TW * (NT * 16 + 8);      // halo tile / output staging share xs
   __shared__ __attribute__((aligned(16))) zt_bf16 ws[K * K * NT * 16 * CP];
-  __shared__ __attribute__((aligned(16))) zt_bf16 xs[IR * IC * CP];
+  __shared__ __attribute__((aligned(16))) zt_bf16 xs[XS_HALO > XS_STAGE ? XS_HALO : XS_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -597,7 +598,58 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
 
     const int tx = tile % a.tilesX, ty = tile / a.tilesX;
     const int oy = ty * PTH + wave, ox0 = tx * TW;
-    if (oy < a.Ho) {
+    if (a.out_mode == 0) {
+      // bf16 nhwc output: transpose the accumulators through LDS (wave-private slice of the halo buffer) so that global
+      // traffic is 16 bytes per lane (2-byte stores are store-issue bound: ~15x slower on this layer)
+      constexpr int OP = NT * 16 + 8;                      // staging row pitch (elements)
+      __syncthreads();                                      // every wave is done reading xs
+      zt_bf16* st = xs + wave * (TW * OP);
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        const int co = co0 + q * 16 + l15;
+        const float b = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            st[(m * 16 + l4 * 4 + j) * OP + q * 16 + l15] = zt_f2bf(apply_act(a.alpha * (acc[m][q][j] + b), a.act));
+      }
+      // same wave wrote and reads: LDS ops of one wave complete in order, so no workgroup barrier is needed; the wave barrier
+      // only pins the compiler's (and the test emulator's) ordering of the two phases
+      __builtin_amdgcn_wave_barrier();
+      if (oy < a.Ho) {
+        for (int e = lane; e < TW * NT * 2; e += 64) {
+          const int p = e / (NT * 2), c8 = (e % (NT * 2)) * 8;
+          const int ox = ox0 + p, co = co0 + c8;
+          if (ox < a.Wo && co < a.Cout) {
+            uint4 v = *reinterpret_cast<const uint4*>(st + p * OP + c8);
+            const size_t pix = (size_t)oy * a.Wo + ox;
+            if (a.epi) {
+              uint4 u = *reinterpret_cast<const uint4*>(a.aux + pix * a.ldaux + co);
+              zt_bf16 tv[8], tu[8];
+              __builtin_memcpy(tv, &v, 16);
+              __builtin_memcpy(tu, &u, 16);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                float fv = zt_bf2f(tv[k]), fu = zt_bf2f(tu[k]);
+                if (a.epi == 1) fv *= (fu > 0.f ? 1.f : 0.2f);
+                else if (a.epi == 2) fv *= (fu > 0.f ? 1.f : 0.f);
+                else fv += fu;
+                tv[k] = zt_f2bf(fv);
+              }
+              __builtin_memcpy(&v, tv, 16);
+            }
+            zt_bf16* dst = (zt_bf16*)a.y + pix * a.ldy + co;
+            if (co + 8 <= a.Cout) *reinterpret_cast<uint4*>(dst) = v;
+            else {
+              zt_bf16 tv[8];
+              __builtin_memcpy(tv, &v, 16);
+              for (int k = 0; k < 8 && co + k < a.Cout; ++k) dst[k] = tv[k];
+            }
+          }
+        }
+      }
+    } else if (oy < a.Ho) {
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
         const int co = co0 + q * 16 + l15;
@@ -618,8 +670,7 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
                   else v += u;
                 }
                 if (a.out_mode == 1) ((float*)a.y)[(size_t)co * a.ldy + pix] = v;
-                else if (a.out_mode == 2) ((float*)a.y)[pix * a.ldy + co] = v;
-                else ((zt_bf16*)a.y)[pix * a.ldy + co] = zt_f2bf(v);
+                else ((float*)a.y)[pix * a.ldy + co] = v;
               }
             }
           }
