@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Tuning tool (GPU box): time the bf16 convolution variants on the 1080p Enhancer layer, with ablations."""
+import importlib
+import sys
+import os
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ops_mod = importlib.import_module("zero-tig_amd.ops")
+lib_mod = importlib.import_module("zero-tig_amd.lib")
+ops = ops_mod.Ops(lib_mod.get_lib())
+dev = torch.device("cuda:0")
+H, W = 1080, 1920
+
+
+def run(cin, cout, k, variant, epi=0, iters=10):
+    x = (torch.randn(1, H, W, cin, device=dev) * 0.5).bfloat16()
+    w = torch.randn(cout, cin, k, k, device=dev) * 0.05
+    wd = ops.repack_weight_bf16(w)
+    aux = x if epi else None
+    out = torch.empty(1, H, W, (cout + 7) // 8 * 8, device=dev, dtype=torch.bfloat16)
+    for _ in range(2):
+        ops.conv2d_bf16(ops_mod.CV(x), wd, None, cout, k, k, (k // 2, k // 2), "relu", out=out, aux=aux, epi=epi, variant=variant)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.conv2d_bf16(ops_mod.CV(x), wd, None, cout, k, k, (k // 2, k // 2), "relu", out=out, aux=aux, epi=epi, variant=variant)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+names = {1: "ws full", 2: "tiled", 17: "ws no-mfma", 18: "ws no-epilogue", 20: "ws no-prefetch", 19: "ws no-mfma no-epi", 23: "ws nothing but staging"}
+for (cin, cout, k) in ((64, 64, 3), (48, 48, 3)):
+    for v in (1, 2, 17, 18, 20, 19, 23):
+        print("c%d->%d k%d  %-24s %8.1f us" % (cin, cout, k, names[v], run(cin, cout, k, v)), flush=True)
+print("c64->64 k3 ws full + residual epi %8.1f us" % run(64, 64, 3, 1, epi=3))

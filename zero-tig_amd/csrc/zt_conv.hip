@@ -358,11 +358,12 @@ struct ConvArgsH {
   int Ho, Wo, Cout, CoutP, ldk, ldy, ldaux;
   int padH, padW;
   int act, epi, out_mode;      // out_mode: 0 bf16 nhwc, 1 fp32 planar, 2 fp32 nhwc
+  int dbg;                     // tuning ablations (tools/bench_conv.py): 1 skip MFMA loop, 2 skip epilogue, 4 skip prefetch
   float alpha;
   int tilesX, tilesY;
 };
 
-constexpr int HCK = 32, HCKP = 40;
+constexpr int HCK = 32, HCKP = 48;      // 96-byte rows: conflict-free ds_read_b128 for every lane group and pixel shift
 
 // ALL: every tap's weights of the current 32-channel chunk fit in LDS next to the input tile -> 2 barriers per chunk;
 // otherwise weights are staged per kernel row (7x7).  MT = 16-pixel MFMA tiles per wave along x (1 for small feature maps).
@@ -489,7 +490,7 @@ int launch_conv_h(const ConvArgsH& a, int NT, unsigned gx, hipStream_t stream) {
   constexpr int IRc = (TH - 1) * S + KH, ICc = (16 * MT - 1) * S + KW;
 #define ZT_CH(nt)                                                                                             \
   {                                                                                                           \
-    constexpr bool all = (KH * KW * nt * 16 + IRc * ICc) * HCKP * 2 <= 64 * 1024;                             \
+    constexpr bool all = (KH * KW * nt * 16 + IRc * ICc) * HCKP * 2 <= 72 * 1024;                             \
     hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all>), grid, block, 0, stream, a);           \
   }
   switch (NT) {
@@ -510,7 +511,7 @@ constexpr int PTH = 8;
 
 template <int K, int NT, int CCH>
 __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntiles) {
-  constexpr int CP = CCH * 32 + 8;
+  constexpr int CP = CCH == 2 ? 80 : 48;       // 160 B / 96 B row pitch: conflict-free ds_read_b128 (brute-forced over lane groups)
   constexpr int IR = PTH + K - 1, IC = TW + K - 1;
   constexpr int NPF = (IR * IC * CCH * 4 + 511) / 512;           // 16-byte prefetch registers per thread
   constexpr int XS_HALO = IR * IC * CP, XS_STAGE = PTH * TW * (NT * 16 + 8);      // halo tile / output staging share xs
@@ -570,13 +571,14 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
     }
     __syncthreads();
     const int next = tile + gridDim.x;
-    if (next < ntiles) prefetch(next);
+    if (next < ntiles && !(a.dbg & 4)) prefetch(next);
 
     zt_f32x4 acc[2][NT];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int q = 0; q < NT; ++q) acc[m][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!(a.dbg & 1))
 #pragma unroll
     for (int tap = 0; tap < K * K; ++tap) {
       const int ky = tap / K, kx = tap % K;
@@ -589,16 +591,20 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
 #pragma unroll
         for (int q = 0; q < NT; ++q)
           bv[q] = *reinterpret_cast<const zt_s16x8*>(ws + (tap * NT * 16 + q * 16 + l15) * CP + kc * 32 + 8 * l4);
+        // weights as the A operand, pixels as B: D[row = cout 4*(lane>>4)+j][col = pixel lane&15], i.e. every lane ends up with
+        // 4 CONSECUTIVE output channels of one pixel -> 8-byte LDS staging writes in the epilogue
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(av[m], bv[q], acc[m][q]);
+          for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(bv[q], av[m], acc[m][q]);
       }
     }
 
     const int tx = tile % a.tilesX, ty = tile / a.tilesX;
     const int oy = ty * PTH + wave, ox0 = tx * TW;
-    if (a.out_mode == 0) {
+    if (a.dbg & 2) {
+      if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[1][NT - 1][3];      // keep the accumulators live
+    } else if (a.out_mode == 0) {
       // bf16 nhwc output: transpose the accumulators through LDS (wave-private slice of the halo buffer) so that global
       // traffic is 16 bytes per lane (2-byte stores are store-issue bound: ~15x slower on this layer)
       constexpr int OP = NT * 16 + 8;                      // staging row pitch (elements)
@@ -606,13 +612,19 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
       zt_bf16* st = xs + wave * (TW * OP);
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
-        const int co = co0 + q * 16 + l15;
-        const float b = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        const int cb = co0 + q * 16 + l4 * 4;
+        float bj[4];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int j = 0; j < 4; ++j) bj[j] = (a.bias && cb + j < a.Cout) ? a.bias[cb + j] : 0.f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            st[(m * 16 + l4 * 4 + j) * OP + q * 16 + l15] = zt_f2bf(apply_act(a.alpha * (acc[m][q][j] + b), a.act));
+        for (int m = 0; m < 2; ++m) {
+          uint2 pk;
+          pk.x = (unsigned)zt_f2bf(apply_act(a.alpha * (acc[m][q][0] + bj[0]), a.act)) |
+                 ((unsigned)zt_f2bf(apply_act(a.alpha * (acc[m][q][1] + bj[1]), a.act)) << 16);
+          pk.y = (unsigned)zt_f2bf(apply_act(a.alpha * (acc[m][q][2] + bj[2]), a.act)) |
+                 ((unsigned)zt_f2bf(apply_act(a.alpha * (acc[m][q][3] + bj[3]), a.act)) << 16);
+          *reinterpret_cast<uint2*>(st + (m * 16 + l15) * OP + q * 16 + l4 * 4) = pk;
+        }
       }
       // same wave wrote and reads: LDS ops of one wave complete in order, so no workgroup barrier is needed; the wave barrier
       // only pins the compiler's (and the test emulator's) ordering of the two phases
@@ -652,14 +664,14 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
     } else if (oy < a.Ho) {
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
-        const int co = co0 + q * 16 + l15;
-        if (co < a.Cout) {
-          const float b = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
+        for (int j = 0; j < 4; ++j) {
+          const int co = co0 + q * 16 + l4 * 4 + j;
+          if (co < a.Cout) {
+            const float b = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int ox = ox0 + m * 16 + l4 * 4 + j;
+            for (int m = 0; m < 2; ++m) {
+              const int ox = ox0 + m * 16 + l15;
               if (ox < a.Wo) {
                 float v = apply_act(a.alpha * (acc[m][q][j] + b), a.act);
                 const size_t pix = (size_t)oy * a.Wo + ox;
@@ -950,6 +962,8 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   a.Wo = (W + 2 * padW - KW) / stride + 1;
   a.Cout = Cout; a.CoutP = CoutP; a.ldk = ldk; a.ldy = ldy; a.ldaux = ldaux;
   a.padH = padH; a.padW = padW; a.act = act; a.epi = epi; a.out_mode = out_mode; a.alpha = alpha;
+  a.dbg = variant >= 16 ? (variant - 16) : 0;
+  if (variant >= 16) variant = 1;
   ZT_REQUIRE(a.Ho > 0 && a.Wo > 0);
   a.tilesY = zt_cdiv(a.Ho, TH);
   int c16 = (Cout + 15) / 16;
