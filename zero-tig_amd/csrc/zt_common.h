@@ -122,3 +122,16 @@ __device__ __forceinline__ zt_f32x4 zt_mfma_bf16(zt_s16x8 a, zt_s16x8 b, zt_f32x
 __device__ __forceinline__ zt_s16x4 zt_lds_read_tr16(const zt_bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) zt_s16x4*)p);
 }
+
+// compile-time counted loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int I>
+struct ZtIdx {
+  static constexpr int value = I;
+};
+template <int B, int E, typename F>
+__device__ __forceinline__ void zt_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(ZtIdx<B>{});
+    zt_static_for<B + 1, E>(f);
+  }
+}

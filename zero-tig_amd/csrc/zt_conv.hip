@@ -9,6 +9,7 @@
 // halo tile is staged once in LDS as [ci][row][col] planes (plane stride == 16 mod 32 banks => both MFMA operand
 // reads are bank-conflict free), weights are staged per kernel row.
 #include "zt_common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -507,13 +508,12 @@ int launch_conv_h(const ConvArgsH& a, int NT, unsigned gx, hipStream_t stream) {
 // Cin <= 64): each workgroup (8 waves = 8 output rows x 32 columns) loads ALL its weights into LDS once and then walks
 // pixel tiles grid-stride; the next tile's halo is prefetched into registers while the MFMAs of the current one run
 // (two barriers per tile).  LDS rows are [pixel | cout][CCH*32 + 8] bf16 (144 B or 80 B pitch: conflict-free b128 reads).
-constexpr int PTH = 8;
-
-template <int K, int NT, int CCH>
-__global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntiles) {
+template <int K, int NT, int CCH, int PTH>
+__global__ void __launch_bounds__(64 * PTH) conv_ws_bf16_kernel(ConvArgsH a, int ntiles) {
+  constexpr int NTHR = 64 * PTH;
   constexpr int CP = CCH == 2 ? 80 : 48;       // 160 B / 96 B row pitch: conflict-free ds_read_b128 (brute-forced over lane groups)
   constexpr int IR = PTH + K - 1, IC = TW + K - 1;
-  constexpr int NPF = (IR * IC * CCH * 4 + 511) / 512;           // 16-byte prefetch registers per thread
+  constexpr int NPF = (IR * IC * CCH * 4 + NTHR - 1) / NTHR;     // 16-byte prefetch registers per thread
   constexpr int XS_HALO = IR * IC * CP, XS_STAGE = PTH * TW * (NT * 16 + 8);      // halo tile / output staging share xs
   __shared__ __attribute__((aligned(16))) zt_bf16 ws[K * K * NT * 16 * CP];
   __shared__ __attribute__((aligned(16))) zt_bf16 xs[XS_HALO > XS_STAGE ? XS_HALO : XS_STAGE];
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
   const int co0 = blockIdx.y * (NT * 16);
   constexpr int pad = (K - 1) / 2;
 
-  for (int e = tid; e < K * K * NT * 16 * CCH * 4; e += 512) {
+  for (int e = tid; e < K * K * NT * 16 * CCH * 4; e += NTHR) {
     int q = e % (CCH * 4);
     int r = e / (CCH * 4);
     int co = r % (NT * 16), tap = r / (NT * 16);
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
     const int gy0 = ty * PTH - pad, gx0 = tx * TW - pad;
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      int e = tid + i * 512;
+      int e = tid + i * NTHR;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (e < IR * IC * CCH * 4) {
         int q = e % (CCH * 4), p = e / (CCH * 4);
@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
   for (; tile < ntiles; tile += gridDim.x) {
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      int e = tid + i * 512;
+      int e = tid + i * NTHR;
       if (e < IR * IC * CCH * 4) *reinterpret_cast<uint4*>(xs + (e / (CCH * 4)) * CP + (e % (CCH * 4)) * 8) = pf[i];
     }
     __syncthreads();
@@ -578,26 +578,35 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int q = 0; q < NT; ++q) acc[m][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!(a.dbg & 1))
-#pragma unroll
-    for (int tap = 0; tap < K * K; ++tap) {
-      const int ky = tap / K, kx = tap % K;
-#pragma unroll
-      for (int kc = 0; kc < CCH; ++kc) {
-        zt_s16x8 av[2], bv[NT];
+    if (!(a.dbg & 1)) {
+      // software-pipelined over the K*K*CCH (tap, channel-half) steps: the fragments of step i+1 are in flight while the
+      // MFMAs of step i issue.  Weights are the A operand, pixels the B operand: D[row = cout 4*(lane>>4)+j][col = pixel
+      // lane&15], i.e. every lane ends up with 4 CONSECUTIVE output channels of one pixel (8-byte staging writes below).
+      constexpr int NSTEP = K * K * CCH;
+      zt_s16x8 av[2][2], bv[2][NT];
+      const zt_bf16* xb = xs + (wave * IC + l15) * CP + 8 * l4;
+      const zt_bf16* wb = ws + l15 * CP + 8 * l4;
+#define ZT_LOADF(buf, step)                                                                                         \
+  {                                                                                                                 \
+    constexpr int tap_ = (step) / CCH, kc_ = (step) % CCH, ky_ = tap_ / K, kx_ = tap_ % K;                          \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) av[buf][m] =                                                      \
+        *reinterpret_cast<const zt_s16x8*>(xb + (ky_ * IC + m * 16 + kx_) * CP + kc_ * 32);                         \
+    _Pragma("unroll") for (int q = 0; q < NT; ++q) bv[buf][q] =                                                     \
+        *reinterpret_cast<const zt_s16x8*>(wb + (tap_ * NT * 16 + q * 16) * CP + kc_ * 32);                         \
+  }
+      ZT_LOADF(0, 0)
+      zt_static_for<0, NSTEP>([&](auto step_c) {
+        constexpr int step = decltype(step_c)::value;
+        constexpr int cur = step & 1;
+        if constexpr (step + 1 < NSTEP) ZT_LOADF(cur ^ 1, step + 1)
+        __builtin_amdgcn_sched_barrier(0);      // keep the next step's LDS reads ahead of this step's MFMAs (hipcc re-serialises them otherwise)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-          av[m] = *reinterpret_cast<const zt_s16x8*>(xs + ((wave + ky) * IC + m * 16 + l15 + kx) * CP + kc * 32 + 8 * l4);
 #pragma unroll
-        for (int q = 0; q < NT; ++q)
-          bv[q] = *reinterpret_cast<const zt_s16x8*>(ws + (tap * NT * 16 + q * 16 + l15) * CP + kc * 32 + 8 * l4);
-        // weights as the A operand, pixels as B: D[row = cout 4*(lane>>4)+j][col = pixel lane&15], i.e. every lane ends up with
-        // 4 CONSECUTIVE output channels of one pixel -> 8-byte LDS staging writes in the epilogue
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(bv[q], av[m], acc[m][q]);
-      }
+          for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(bv[cur][q], av[cur][m], acc[m][q]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#undef ZT_LOADF
     }
 
     const int tx = tile % a.tilesX, ty = tile / a.tilesX;
@@ -610,6 +619,10 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
       constexpr int OP = NT * 16 + 8;                      // staging row pitch (elements)
       __syncthreads();                                      // every wave is done reading xs
       zt_bf16* st = xs + wave * (TW * OP);
+      // none / ReLU / LeakyReLU(0.2) are max(v, slope*v) with slope 1 / 0 / 0.2: branch-free on the hot path (a runtime switch
+      // expanded over the 32 accumulators blew up the code size and the instruction cache); other activations go the slow way.
+      const bool simple_act = a.act <= 2;
+      const float slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.2f);
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
         const int cb = co0 + q * 16 + l4 * 4;
@@ -618,11 +631,19 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
         for (int j = 0; j < 4; ++j) bj[j] = (a.bias && cb + j < a.Cout) ? a.bias[cb + j] : 0.f;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = a.alpha * (acc[m][q][j] + bj[j]);
+            v[j] = fmaxf(v[j], slope * v[j]);
+          }
+          if (!simple_act) {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) v[j] = apply_act(a.alpha * (acc[m][q][j] + bj[j]), a.act);
+          }
           uint2 pk;
-          pk.x = (unsigned)zt_f2bf(apply_act(a.alpha * (acc[m][q][0] + bj[0]), a.act)) |
-                 ((unsigned)zt_f2bf(apply_act(a.alpha * (acc[m][q][1] + bj[1]), a.act)) << 16);
-          pk.y = (unsigned)zt_f2bf(apply_act(a.alpha * (acc[m][q][2] + bj[2]), a.act)) |
-                 ((unsigned)zt_f2bf(apply_act(a.alpha * (acc[m][q][3] + bj[3]), a.act)) << 16);
+          pk.x = (unsigned)zt_f2bf(v[0]) | ((unsigned)zt_f2bf(v[1]) << 16);
+          pk.y = (unsigned)zt_f2bf(v[2]) | ((unsigned)zt_f2bf(v[3]) << 16);
           *reinterpret_cast<uint2*>(st + (m * 16 + l15) * OP + q * 16 + l4 * 4) = pk;
         }
       }
@@ -694,13 +715,21 @@ __global__ void __launch_bounds__(512) conv_ws_bf16_kernel(ConvArgsH a, int ntil
 }
 
 template <int K>
-int launch_conv_ws(const ConvArgsH& a, int NT, int CCH, hipStream_t stream) {
+int launch_conv_ws(ConvArgsH& a, int NT, int CCH, int pth, hipStream_t stream) {
   int c16 = (a.Cout + 15) / 16;
+  a.tilesY = zt_cdiv(a.Ho, pth);
   int ntiles = a.tilesX * a.tilesY;
-  int per_cu = (CCH == 1 && NT <= 3) ? 2 : 1;
+  // LDS per workgroup decides how many are co-resident per CU (phases of different workgroups overlap HBM reads, MFMA and stores)
+  int cp = CCH == 2 ? 80 : 48;
+  int lds = 2 * (K * K * NT * 16 * cp + (pth + K - 1) * (TW + K - 1) * cp);
+  int per_cu = 160 * 1024 / (lds + 1024);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
   int gx = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
-  dim3 grid(gx, (c16 + NT - 1) / NT), block(512);
-#define ZT_WS(nt, cch) hipLaunchKernelGGL((conv_ws_bf16_kernel<K, nt, cch>), grid, block, 0, stream, a, ntiles); return 0
+  dim3 grid(gx, (c16 + NT - 1) / NT), block(64 * pth);
+#define ZT_WS(nt, cch)                                                                                                   \
+  if (pth == 8) hipLaunchKernelGGL((conv_ws_bf16_kernel<K, nt, cch, 8>), grid, block, 0, stream, a, ntiles);            \
+  else hipLaunchKernelGGL((conv_ws_bf16_kernel<K, nt, cch, 4>), grid, block, 0, stream, a, ntiles);                     \
+  return 0
   if (CCH == 1) {
     if (NT == 1) { ZT_WS(1, 1); }
     if (NT == 2) { ZT_WS(2, 1); }
@@ -976,11 +1005,17 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   // full-resolution stride-1 layers of the enhancement nets: persistent weight-stationary kernel
   const bool ws_ok = N == 1 && stride == 1 && KH == KW && (KH == 1 || KH == 3) && padH == KH / 2 && padW == KW / 2 && Cin <= 64 && !x2;
   ZT_REQUIRE(variant != 1 || ws_ok);
-  if (variant != 2 && ws_ok && (variant == 1 || (long long)zt_cdiv(a.Wo, TW) * zt_cdiv(a.Ho, PTH) >= 1024)) {
+  if (variant != 2 && ws_ok && (variant == 1 || (long long)zt_cdiv(a.Wo, TW) * zt_cdiv(a.Ho, 8) >= 1024)) {
     a.tilesX = zt_cdiv(a.Wo, TW);
-    a.tilesY = zt_cdiv(a.Ho, PTH);
     int CCH = Cin <= 32 ? 1 : 2;
-    int rcw = (KH == 3) ? launch_conv_ws<3>(a, NT, CCH, stream) : launch_conv_ws<1>(a, NT, CCH, stream);
+    int pth = 8, nt = NT;
+    const char* cfg = getenv("ZT_WS_CFG");          // tuning hook: "<rows><nt>", e.g. "42" = 4-row tiles, 32 couts per workgroup
+    if (cfg && cfg[0] && cfg[1]) {
+      pth = cfg[0] == '4' ? 4 : 8;
+      int want = cfg[1] - '0';
+      if (want >= 1 && want <= 4 && want <= NT) nt = want;
+    }
+    int rcw = (KH == 3) ? launch_conv_ws<3>(a, nt, CCH, pth, stream) : launch_conv_ws<1>(a, nt, CCH, pth, stream);
     if (rcw) return rcw;
     ZT_LAUNCH_CHECK();
     return ZT_OK;
