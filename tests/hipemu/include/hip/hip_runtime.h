@@ -154,6 +154,7 @@ template <class T> static inline T __shfl(T v, int src, int = 64) { return emu::
 template <class T> static inline T __builtin_amdgcn_readfirstlane(T v) { return v; }
 static inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_s_sleep(int) {}
 
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }

@@ -533,28 +533,32 @@ __global__ void __launch_bounds__(64 * PTH) conv_ws_bf16_kernel(ConvArgsH a, int
     *reinterpret_cast<uint4*>(ws + (tap * NT * 16 + co) * CP + c) = v;
   }
 
+  // the halo element a thread fetches is the same for every tile: precompute its (row, col, channel) once
   uint4 pf[NPF];
+  int pf_iy[NPF], pf_ix[NPF], pf_c[NPF];
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    int e = tid + i * NTHR;
+    int q = e % (CCH * 4), p = e / (CCH * 4);
+    pf_iy[i] = e < IR * IC * CCH * 4 ? p / IC : -100000;       // out-of-range slots never pass the bounds test
+    pf_ix[i] = p % IC;
+    pf_c[i] = q * 8;
+  }
   auto prefetch = [&](int tile) {
     const int tx = tile % a.tilesX, ty = tile / a.tilesX;
     const int gy0 = ty * PTH - pad, gx0 = tx * TW - pad;
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      int e = tid + i * NTHR;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (e < IR * IC * CCH * 4) {
-        int q = e % (CCH * 4), p = e / (CCH * 4);
-        int iy = p / IC, ixx = p - iy * IC;
-        int gy = gy0 + iy, gx = gx0 + ixx;
-        int c = q * 8;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Cin) {
-          v = *reinterpret_cast<const uint4*>(a.x + ((size_t)gy * a.W + gx) * a.ldx + c);
-          if (c + 8 > a.Cin) {
-            zt_bf16 tmp[8];
-            __builtin_memcpy(tmp, &v, 16);
-            for (int j = 0; j < 8; ++j)
-              if (c + j >= a.Cin) tmp[j] = 0;
-            __builtin_memcpy(&v, tmp, 16);
-          }
+      const int gy = gy0 + pf_iy[i], gx = gx0 + pf_ix[i], c = pf_c[i];
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Cin) {
+        v = *reinterpret_cast<const uint4*>(a.x + ((size_t)gy * a.W + gx) * a.ldx + c);
+        if (c + 8 > a.Cin) {
+          zt_bf16 tmp[8];
+          __builtin_memcpy(tmp, &v, 16);
+          for (int j = 0; j < 8; ++j)
+            if (c + j >= a.Cin) tmp[j] = 0;
+          __builtin_memcpy(&v, tmp, 16);
         }
       }
       pf[i] = v;
@@ -563,6 +567,12 @@ __global__ void __launch_bounds__(64 * PTH) conv_ws_bf16_kernel(ConvArgsH a, int
 
   int tile = blockIdx.x;
   if (tile < ntiles) prefetch(tile);
+  // de-phase neighbouring workgroups by ~half a tile so that HBM reads, MFMA work and HBM writes of different CUs interleave
+  // instead of the whole chip moving through the same phase in lock-step (speed only; no correctness dependence)
+  if ((a.dbg & 8) == 0 && (blockIdx.x & 1)) {
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
+  }
   for (; tile < ntiles; tile += gridDim.x) {
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
