@@ -85,14 +85,15 @@ int zt_norm_finalize_f32(const float* partial, int nblk, int N, int C, long long
 int zt_norm_apply_nhwc(const void* x, int dt, int ldx, const float* scale, const float* shift, const void* res, int ldres,
                            void* y, int ldy, int N, int HW, int C, int inner_relu, int outer_relu, zt_stream_t stream);
 /* backward of y = ReLU(BN_train(z)): stage 1 partial sums of dyh = dy*[bn>0] and dyh*zhat; generic partial reduction;
- * stage 2 dz = gamma*rstd*(dyh - mean(dyh) - zhat*mean(dyh*zhat)) with sums = [sum dyh (C) | sum dyh*zhat (C)] */
+ * stage 2 dz = gamma*rstd*(dyh - mean(dyh) - zhat*mean(dyh*zhat)) with sums = [sum dyh (C) | sum dyh*zhat (C)];
+ * eval_mode = 1: statistics are constants (running stats): dz = gamma*rstd*dyh (reference epochs >= 1, train.py:138) */
 int zt_bn_bwd_reduce(const void* dy, int dt, int lddy, const void* z, int ldz, const float* scale, const float* shift,
                          const float* mean, const float* rstd, int HW, int C, int nblk, float* partial, zt_stream_t stream);
 int zt_partial_reduce_f32(const float* partial, int nblk, int stride, int n, float* out, int accumulate, float* out2,
                           zt_stream_t stream);
 int zt_bn_bwd_apply(const void* dy, int dt, int lddy, const void* z, int ldz, const float* scale, const float* shift,
                         const float* mean, const float* rstd, const float* sums, void* dz, int lddz, int HW, int C,
-                        zt_stream_t stream);
+                        int eval_mode, zt_stream_t stream);
 
 
 /* ---- element-wise stages of Network.forward (model.py:144-203) and their backward (zt_glue.hip); planar [3][H][W], H,W even */

@@ -224,3 +224,31 @@ def test_bf16_sequence_flow_and_psnr(backend, synth, oracle):
     assert abs(float(l1) - float(g["loss1"])) <= 2e-2 * abs(float(g["loss1"]))
     wp_err = float((net.last_H3_wp.cpu() - torch.from_numpy(g["wpH"])).abs().mean())
     assert wp_err < 5e-3, wp_err
+
+
+def test_eval_mode_bn_training_quirk(backend, synth, oracle):
+    """SURVEY A-14: from epoch 1 on the reference trains with BatchNorm in eval mode (train.py:138 never switches back).
+    Forward uses running stats, backward treats them as constants; running stats are not updated."""
+    ops, dev, bname = backend
+    H, W, seed = 48, 64, 1
+    x = frames(synth, 1, H, W)[0]
+    st = synth.make_state(seed)
+    st["enhance.conv.1.running_mean"][:] = synth.normal("rm", (64,), 0.0, 0.05, 9)
+    st["enhance.conv.1.running_var"][:] = synth.uniform("rv", (64,), 0.01, 0.05, 9)
+    net = _network(ops, dev, synth, seed, of_scale=3)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()})
+    net = net.to(dev)
+    net.eval()
+    net.is_new_seq = True
+    loss = net._loss(x.to(dev))
+    loss.backward()
+    tr = oracle.OracleTrainer(oracle.to_torch_state(st))
+    tr.training = False
+    ref, _, _, _ = tr.loss(x, True)
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-4 * abs(float(ref.detach()))
+    for n, p in net.named_parameters():
+        if p.requires_grad and not n.startswith("enhance.blocks"):
+            assert rel_l2(p.grad, tr.W[n].grad) < 2e-3, (n, rel_l2(p.grad, tr.W[n].grad))
+    assert int(net.enhance.conv[1].num_batches_tracked) == 0
+    assert float((net.enhance.conv[1].running_mean.cpu() - torch.from_numpy(st["enhance.conv.1.running_mean"])).abs().max()) == 0.0

@@ -1,0 +1,116 @@
+"""Parity at BASELINE.json's real sizes (GPU only).
+ * config 2 (540x960 frame pair, fp32): enhance + RAFT flow + backward warp against the CPU oracle on the same inputs;
+ * 1080x1920: integer contracts bit-exact against the oracle (warp taps, equalize), and size-independent properties of the
+   kernels where running the oracle would take minutes (adjointness, determinism, loss-term consistency, bf16 vs fp32)."""
+import argparse
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import frames
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(ops, dev, synth, seed, of_scale, precision="fp32"):
+    net_mod = importlib.import_module("zero-tig_amd.network")
+    net = net_mod.Network(argparse.Namespace(dataset="RLV", of_scale=of_scale), ops=ops, precision=precision)
+    st = synth.make_state(seed)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()})
+    return net.to(dev).train()
+
+
+def test_540p_pair_forward_flow_warp_vs_oracle(hip_ops, synth, oracle):
+    ops, dev = hip_ops
+    H, W, ofs = 540, 960, 3              # RAFT input 180x320 -> padded 184x320 (flow_up keeps the padded size; scales swapped)
+    xs = frames(synth, 2, H, W)
+    net = _net(ops, dev, synth, 1, ofs)
+    Wt = oracle.to_torch_state(synth.make_state(1))
+    cache = {}
+    with torch.no_grad():
+        for t, x in enumerate(xs):
+            net.is_new_seq = (t == 0)
+            outs = net(x.to(dev))
+            ref, aux = oracle.network_forward(Wt, cache, x, t == 0, ofs, training=True)
+            cache["last_H3"], cache["last_s3"] = ref[13], ref[14]
+            net.update_H3(outs[13], outs[14])
+            tol = 2e-5 if t == 0 else 3e-4
+            for i in (2, 3, 6, 13, 14):                      # L2, s2, H2, H3, s3
+                err = float((outs[i].cpu() - ref[i]).abs().max())
+                assert err < tol, (t, oracle.FORWARD_NAMES[i], err)
+            if t == 1:
+                err_w = float((net.last_H3_wp.cpu() - aux["wpH"]).abs().max())
+                assert err_w < 3e-4, err_w
+            mism = float((outs[18].cpu() != ref[18]).float().mean())
+            assert mism <= 1e-3, mism
+
+
+def test_1080p_integer_contracts_bit_exact(hip_ops, synth, oracle):
+    ops, dev = hip_ops
+    H, W = 1080, 1920
+    g = torch.Generator().manual_seed(0)
+    flow = torch.randn(1, 2, 360, 640, generator=g) * 3.0
+    img = torch.rand(1, 3, H, W, generator=g)
+    out, _, taps = ops.warp2(flow.to(dev), img.to(dev), None, want_taps=True)
+    assert torch.equal(taps.cpu(), oracle.warp_taps(flow, H, W)[0])
+    assert torch.equal(out.cpu(), oracle.warp_tensor(flow, img))
+    x255 = (torch.rand(1, 3, 360, 640, generator=g) ** 2 * 255.0)
+    q, hist, lut = ops.equalize_prepare(x255.to(dev))
+    assert int(hist.sum()) == 3 * 360 * 640
+    ref = oracle.equalize_u8(x255.to(torch.uint8))
+    got = torch.gather(lut.cpu().long(), 1, q.cpu().long()).view(1, 3, 360, 640).to(torch.uint8)
+    assert torch.equal(got, ref)
+    a = ops.resize_bilinear(img.to(dev), 360, 640, 255.0)
+    assert torch.equal(a.cpu(), torch.nn.functional.interpolate(img, (360, 640), mode="bilinear") * 255)
+
+
+def test_1080p_adjoints(hip_ops):
+    ops, dev = hip_ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(1, 3, 1080, 1920, generator=g).to(dev)
+    y = torch.rand(1, 3, 1080, 1920, generator=g).to(dev)
+    yh = torch.rand(1, 3, 540, 960, generator=g).to(dev)
+
+    def dot(a, b):
+        return float((a.double() * b.double()).sum())
+    assert abs(dot(ops.blur21(x), y) - dot(x, ops.blur21_adj(y))) <= 1e-6 * abs(dot(x, y))
+    assert abs(dot(ops.box5_reflect(x), y) - dot(x, ops.box5_reflect_adj(y))) <= 1e-6 * abs(dot(x, y))
+    a, b = ops.pair_down(x)
+    assert abs(dot(a, yh) + dot(b, yh) - dot(x, ops.pair_down_adj(yh, yh, 1080, 1920))) <= 1e-6 * abs(dot(x, y))
+
+
+def test_1080p_step_determinism_and_consistency(hip_ops, synth):
+    ops, dev = hip_ops
+    x = frames(synth, 2, 1080, 1920)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        for rep in range(2 if prec == "fp32" else 1):
+            net = _net(ops, dev, synth, 1, 3, prec)
+            losses, grads = [], None
+            for t in range(2):
+                net.zero_grad()
+                net.is_new_seq = (t == 0)
+                loss = net._loss(x[t].to(dev))
+                loss.backward()
+                losses.append(float(loss.detach()))
+            terms = net.last_terms.cpu()
+            assert abs(float(terms.double().sum()) - losses[-1]) <= 1e-5 * abs(losses[-1])      # 17 weighted terms add up
+            grads = torch.cat([p.grad.flatten() for p in net.parameters() if p.requires_grad]).cpu()
+            assert torch.isfinite(grads).all()
+            res[(prec, rep)] = (losses, grads, net.last_H3.cpu())
+    # no float atomics anywhere: the whole 1080p step (incl. RAFT) is bit-reproducible run to run
+    assert res[("fp32", 0)][0] == res[("fp32", 1)][0]
+    assert torch.equal(res[("fp32", 0)][1], res[("fp32", 1)][1])
+    # bf16 throughput mode tracks the fp32 parity mode
+    lf, lb = res[("fp32", 0)][0][1], res[("bf16", 0)][0][1]
+    assert abs(lf - lb) <= 2e-2 * abs(lf), (lf, lb)
+    gf, gb = res[("fp32", 0)][1].double(), res[("bf16", 0)][1].double()
+    assert float((gf - gb).norm() / gf.norm()) < 0.1
+    clean = torch.from_numpy(synth.clean_frame(1, 1080, 1920)).float()[None]
+
+    def psnr(a, b):
+        a8, b8 = torch.clamp(torch.round(a * 255), 0, 255), torch.clamp(torch.round(b * 255), 0, 255)
+        return 10 * np.log10(255.0 ** 2 / float(((a8 - b8) ** 2).mean()))
+    assert abs(psnr(res[("fp32", 0)][2], clean) - psnr(res[("bf16", 0)][2], clean)) <= 0.01

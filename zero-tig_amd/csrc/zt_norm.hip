@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ shift, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ sums,
                                                            float inv_n, T* __restrict__ dz, int lddz, int C,
-                                                           long long total4) {
+                                                           int eval_mode, long long total4) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
   const int Q = C >> 2;
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
   {                                                           \
     float gg = (v.f * sc.f + sf.f > 0.f) ? g.f : 0.f;         \
     float zh = (v.f - mu.f) * rs.f;                           \
-    o.f = sc.f * (gg - s1.f * inv_n - zh * (s2.f * inv_n));   \
+    o.f = eval_mode ? sc.f * gg : sc.f * (gg - s1.f * inv_n - zh * (s2.f * inv_n));   \
   }
   ZT_BN1(x) ZT_BN1(y) ZT_BN1(z) ZT_BN1(w)
 #undef ZT_BN1
@@ -290,15 +290,15 @@ extern "C" int zt_partial_reduce_f32(const float* partial, int nblk, int stride,
 
 extern "C" int zt_bn_bwd_apply(const void* dy, int dt, int lddy, const void* z, int ldz, const float* scale,
                                const float* shift, const float* mean, const float* rstd, const float* sums,
-                               void* dz, int lddz, int HW, int C, hipStream_t stream) {
+                               void* dz, int lddz, int HW, int C, int eval_mode, hipStream_t stream) {
   ZT_REQUIRE(dy && z && dz && sums && C % 4 == 0);
   long long total4 = (long long)HW * (C / 4);
   if (dt == 0)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, (const float*)dy,
-                       lddy, (const float*)z, ldz, scale, shift, mean, rstd, sums, 1.f / (float)HW, (float*)dz, lddz, C, total4);
+                       lddy, (const float*)z, ldz, scale, shift, mean, rstd, sums, 1.f / (float)HW, (float*)dz, lddz, C, eval_mode, total4);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<zt_bf16>, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, (const zt_bf16*)dy,
-                       lddy, (const zt_bf16*)z, ldz, scale, shift, mean, rstd, sums, 1.f / (float)HW, (zt_bf16*)dz, lddz, C, total4);
+                       lddy, (const zt_bf16*)z, ldz, scale, shift, mean, rstd, sums, 1.f / (float)HW, (zt_bf16*)dz, lddz, C, eval_mode, total4);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

@@ -154,9 +154,9 @@ class Engine:
         df = self._conv(dOv, "enhance.out_conv.0/T", None, 64, 3, None)
         for i in (2, 1, 0):
             sc, sh, mu, rs = stats[i]
-            if not self.training:
-                raise NotImplementedError("backward through eval-mode BatchNorm (reference train.py:138 quirk) is not built yet")
-            dz = o.bn_relu_bwd(df, zs[i], sc, sh, mu, rs, g["enhance.conv.1.weight"], g["enhance.conv.1.bias"])
+            # eval-mode BN (the reference trains epochs >= 1 like this, train.py:138 / SURVEY A-14): running stats are constants
+            dz = o.bn_relu_bwd(df, zs[i], sc, sh, mu, rs, g["enhance.conv.1.weight"], g["enhance.conv.1.bias"],
+                               eval_mode=not self.training)
             self._wgrad(feats[i], dz, 64, 3, "enhance.conv.0.weight")
             self._bias_grad(dz, 64, "enhance.conv.0.bias")
             df = self._conv(dz, "enhance.conv.0/T", None, 64, 3, None, aux=df, epi=3)

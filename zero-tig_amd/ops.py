@@ -252,8 +252,9 @@ class Ops:
     def partial_reduce(self, part, nblk, stride, n, out=None, accumulate=False, out2=None):
         self.lib.call("zt_partial_reduce_f32", part, nblk, stride, n, out, int(accumulate), out2, self._s(part))
 
-    def bn_relu_bwd(self, dy, z, scale, shift, mean, rstd, dgamma, dbeta, out=None):
-        """backward of ReLU(BN_train(z)) for N == 1; accumulates dgamma/dbeta; returns dz (NHWC)."""
+    def bn_relu_bwd(self, dy, z, scale, shift, mean, rstd, dgamma, dbeta, out=None, eval_mode=False):
+        """backward of ReLU(BN(z)) for N == 1 (train-mode batch statistics, or eval_mode: running statistics are constants);
+        accumulates dgamma/dbeta; returns dz (NHWC)."""
         dy, z = _cv(dy), _cv(z)
         HW, C = z.H * z.W, z.C
         nblk = self._nblk(HW)
@@ -267,7 +268,8 @@ class Ops:
         if out is None:
             out = torch.empty((1, z.H, z.W, C), dtype=z.t.dtype, device=z.t.device)
         o = _cv(out)
-        self.lib.call("zt_bn_bwd_apply", dy.ptr, _dt(z.t), dy.ld, z.ptr, z.ld, scale, shift, mean, rstd, sums, o.ptr, o.ld, HW, C, self._s(z.t))
+        self.lib.call("zt_bn_bwd_apply", dy.ptr, _dt(z.t), dy.ld, z.ptr, z.ld, scale, shift, mean, rstd, sums, o.ptr, o.ld, HW, C,
+                      int(eval_mode), self._s(z.t))
         return out
 
     # ---- RAFT specific (zt_raft.hip) --------------------------------------------------------------------------
