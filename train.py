@@ -35,6 +35,8 @@ parser.add_argument("--lowlight_images_path", type=str, default="", help="input 
 parser.add_argument("--of_scale", type=int, default=3, help="downscale factor for optical flow")
 parser.add_argument("--dataset", type=str, default="RLV", help="dataset name")
 parser.add_argument("--num_workers", type=int, default=0, help="dataloader workers")
+parser.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"], help="bf16 throughput mode / fp32 parity mode")
+parser.add_argument("--reference_eval_quirk", action="store_true", help="stay in eval() after the first epoch like the reference (train.py:138)")
 
 
 def save_images(tensor):
@@ -68,7 +70,7 @@ def main():
     torch.manual_seed(args.seed)
     logging.info("args = %s", args)
 
-    model = Network(args)
+    model = Network(args, precision=args.precision)
     if rank == 0:
         utils.save(model, os.path.join(args.save, "initial_weights.pt"))
     model.enhance.in_conv.apply(model.enhance_weights_init)
@@ -132,7 +134,8 @@ def main():
                     Image.fromarray(save_images(H3)).save(args.save + "/result/denoise/" + name + "_denoise_" + str(epoch) + ".png", "PNG")
                     Image.fromarray(save_images(H2)).save(args.save + "/result/enhance/" + name + "_enhance_" + str(epoch) + ".png", "PNG")
             # NOTE: the reference stays in eval() from here on (train.py:138, SURVEY A-14); this loop returns to train mode.
-            model.train()
+            if not args.reference_eval_quirk:
+                model.train()
 
 
 if __name__ == "__main__":
