@@ -62,9 +62,10 @@ int zt_conv2d_nhwc_f32(const float* x, const float* x2, int csplit, int ldx, int
                        int KW, int stride, int padH, int padW, int act, float alpha, const float* aux, int ldaux,
                        int epi, zt_stream_t stream);
 /* weight gradient of a stride-1 "same" conv (autograd of the above): grad_w [Cout][Cin][KH][KW] (torch layout)
- * (+)= sum_p x[p+tap][ci] dz[p][co]; slab: workspace for per-workgroup partials (deterministic reduction). */
+ * (+)= sum_p x[p+tap][ci] dz[p][co]; grad_b [Cout] (optional) (+)= sum_p dz[p][co] (bias gradient, folded into the same pass);
+ * slab: workspace for per-workgroup partials (deterministic reduction). */
 int zt_conv2d_wgrad_nhwc_f32(const float* x, int ldx, const float* dz, int lddz, int H, int W, int Cin, int Cout, int KH,
-                             int KW, float* slab, size_t slab_bytes, float* grad_w, int accumulate, zt_stream_t stream);
+                             int KW, float* slab, size_t slab_bytes, float* grad_w, float* grad_b, int accumulate, zt_stream_t stream);
 /* torch weight [Cout][Cin][KH][KW] -> device layout [tap][Cin][ldw] at column offset co_off (transpose_flip = 0), or the
  * data-gradient operator [tap flipped][Cout][ldw] with in/out channels exchanged (transpose_flip = 1). */
 int zt_repack_conv_weight_f32(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int ldw, int co_off,
@@ -195,7 +196,7 @@ int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int csplit, int l
                                 int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout, int KH, int KW, int stride,
                                 int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi, int variant, zt_stream_t stream);
 int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout, int KH, int KW,
-                              float* slab, size_t slab_bytes, float* grad_w, int accumulate, zt_stream_t stream);
+                              float* slab, size_t slab_bytes, float* grad_w, float* grad_b, int accumulate, zt_stream_t stream);
 int zt_repack_conv_weight_bf16(const float* src, void* dst, int Cout, int Cin, int KH, int KW, int CoutP, int ldk, int co_off,
                                int transpose_flip, zt_stream_t stream);
 

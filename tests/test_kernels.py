@@ -183,10 +183,12 @@ def test_conv_wgrad(backend, case):
     xd = CV(_nhwc(x, ldx).to(dev), 0, Cin)
     dzd = CV(_nhwc(dz, (Cout + 3) // 4 * 4).to(dev), 0, Cout)
     gw = torch.full((Cout, Cin, K, K), 7.0, device=dev)
-    ops.conv2d_wgrad(xd, dzd, Cout, K, K, gw, accumulate=False)
+    gb = torch.full((Cout,), 5.0, device=dev)
+    ops.conv2d_wgrad(xd, dzd, Cout, K, K, gw, accumulate=False, grad_b=gb)
     assert maxerr(gw, w.grad) < 5e-5, maxerr(gw, w.grad)
-    ops.conv2d_wgrad(xd, dzd, Cout, K, K, gw, accumulate=True)
-    assert maxerr(gw, 2 * w.grad) < 1e-4
+    assert maxerr(gb, dz.sum(dim=(0, 2, 3))) < 5e-5
+    ops.conv2d_wgrad(xd, dzd, Cout, K, K, gw, accumulate=True, grad_b=gb)
+    assert maxerr(gw, 2 * w.grad) < 1e-4 and maxerr(gb, 2 * dz.sum(dim=(0, 2, 3))) < 1e-4
 
 
 def test_norms(backend):
@@ -387,8 +389,10 @@ def test_conv_wgrad_bf16(backend, case):
     w = torch.zeros(Cout, Cin, K, K, requires_grad=True)
     (F.conv2d(x, w, None, padding=K // 2) * dz).sum().backward()
     gw = torch.full((Cout, Cin, K, K), 3.0, device=dev)
-    ops.conv2d_wgrad_bf16(CV(_nhwc_bf16(x, ldx).to(dev), 0, Cin), CV(_nhwc_bf16(dz, lddz).to(dev), 0, Cout), Cout, K, K, gw)
+    gb = torch.full((Cout,), 3.0, device=dev)
+    ops.conv2d_wgrad_bf16(CV(_nhwc_bf16(x, ldx).to(dev), 0, Cin), CV(_nhwc_bf16(dz, lddz).to(dev), 0, Cout), Cout, K, K, gw, grad_b=gb)
     assert maxerr(gw, w.grad) < 2e-3 * float(w.grad.abs().max()), maxerr(gw, w.grad)
+    assert maxerr(gb, dz.sum(dim=(0, 2, 3))) < 1e-3
 
 
 BF16_GEO = [

@@ -79,11 +79,21 @@ __device__ __forceinline__ float zt_bf2f(zt_bf16 h) {
   __builtin_memcpy(&f, &u, 4);
   return f;
 }
-__device__ __forceinline__ zt_bf16 zt_f2bf(float f) {                   // round to nearest even (finite inputs)
-  unsigned u;
-  __builtin_memcpy(&u, &f, 4);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (zt_bf16)(u >> 16);
+__device__ __forceinline__ zt_bf16 zt_f2bf(float f) {                   // round to nearest even; hipcc emits v_cvt_pk_bf16_f32
+  __bf16 h = (__bf16)f;
+  zt_bf16 r;
+  __builtin_memcpy(&r, &h, 2);
+  return r;
+}
+// two floats -> packed bf16x2 in one dword (low half = a)
+__device__ __forceinline__ unsigned zt_f2bf2(float a, float b) {
+  typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  f2_t v = {a, b};
+  bf2_t h = __builtin_convertvector(v, bf2_t);
+  unsigned r;
+  __builtin_memcpy(&r, &h, 4);
+  return r;
 }
 
 // element access that is generic over the NHWC storage type
@@ -104,8 +114,8 @@ template <> struct ZtIO<zt_bf16> {
   }
   static __device__ __forceinline__ void st4(zt_bf16* p, float4 v) {
     uint2 r;
-    r.x = (unsigned)zt_f2bf(v.x) | ((unsigned)zt_f2bf(v.y) << 16);
-    r.y = (unsigned)zt_f2bf(v.z) | ((unsigned)zt_f2bf(v.w) << 16);
+    r.x = zt_f2bf2(v.x, v.y);
+    r.y = zt_f2bf2(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = r;
   }
   static __device__ __forceinline__ float ld(const zt_bf16* p) { return zt_bf2f(*p); }

@@ -221,6 +221,10 @@ __global__ void __launch_bounds__(256) wgrad_mfma_f32_kernel(WgradArgs a) {
   for (int p = 0; p < PPW; ++p)
 #pragma unroll
     for (int q = 0; q < NT; ++q) acc[p][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of dz, folded in: thread (co = tid % NT16, part = tid / NT16) sums a strided share of each tile
+  constexpr int NPART = 256 / (NT * 16);
+  const int bco = tid % (NT * 16), bpart = tid / (NT * 16);
+  float bsum = 0.f;
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int tx = tile % a.tilesX, ty = tile / a.tilesX;
@@ -262,6 +266,8 @@ __global__ void __launch_bounds__(256) wgrad_mfma_f32_kernel(WgradArgs a) {
       *reinterpret_cast<float4*>(zs + p * COP + c) = v;
     }
     __syncthreads();
+    if (bpart < NPART)
+      for (int p = bpart; p < WTH * WTW; p += NPART) bsum += zs[p * COP + bco];
 #pragma unroll 1
     for (int r = 0; r < WTH; ++r) {
 #pragma unroll
@@ -284,8 +290,8 @@ __global__ void __launch_bounds__(256) wgrad_mfma_f32_kernel(WgradArgs a) {
       }
     }
   }
-  // slab[block][tap][ci16][co16]
-  float* out = a.slab + (size_t)blockIdx.x * (KH * KW * CT * 16 * NT * 16);
+  // slab[block] = [tap][ci16][co16] weights partial, then [co16] bias partial
+  float* out = a.slab + (size_t)blockIdx.x * (KH * KW * CT * 16 * NT * 16 + NT * 16);
 #pragma unroll
   for (int pi = 0; pi < PPW; ++pi) {
     const int pr = wave + 4 * pi;
@@ -298,17 +304,26 @@ __global__ void __launch_bounds__(256) wgrad_mfma_f32_kernel(WgradArgs a) {
           out[((size_t)tap * CT * 16 + cit * 16 + l4 * 4 + j) * (NT * 16) + q * 16 + l15] = acc[pi][q][j];
     }
   }
+  __syncthreads();
+  if (bpart < NPART) zs[bpart * (NT * 16) + bco] = bsum;
+  __syncthreads();
+  if (tid < NT * 16) {
+    float sum = 0.f;
+    for (int k = 0; k < NPART; ++k) sum += zs[k * (NT * 16) + tid];
+    out[KH * KW * CT * 16 * NT * 16 + tid] = sum;
+  }
 }
 
-// grad[co][ci][ky][kx] (+)= sum_slabs slab[s][tap][ci][co].  64 slab elements (co fastest -> coalesced) x 4 slab groups
-// per workgroup; fixed summation order (deterministic).
+// grad_w[co][ci][ky][kx] (+)= sum_slabs slab[s][tap][ci][co]; grad_b[co] (+)= sum_slabs slab[s][bias tail].  64 slab
+// elements (co fastest -> coalesced) x 4 slab groups per workgroup; fixed summation order (deterministic).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int ntap, int CT16,
                                                            int NT16, float* __restrict__ grad, int Cout, int Cin,
-                                                           int accumulate) {
+                                                           int accumulate, float* __restrict__ grad_b) {
   __shared__ float sh[256];
   const int ex = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + ex;
-  const int total = ntap * CT16 * NT16;
+  const int nw = ntap * CT16 * NT16;
+  const int total = nw + NT16;
   float s = 0.f;
   if (e < total) {
     const size_t stride = (size_t)total;
@@ -318,12 +333,17 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   __syncthreads();
   if (sg == 0 && e < total) {
     s = ((sh[ex] + sh[64 + ex]) + sh[128 + ex]) + sh[192 + ex];
-    int co = e % NT16;
-    int ci = (e / NT16) % CT16;
-    int tap = e / (NT16 * CT16);
-    if (co < Cout && ci < Cin) {
-      size_t o = ((size_t)co * Cin + ci) * ntap + tap;
-      grad[o] = accumulate ? grad[o] + s : s;
+    if (e < nw) {
+      int co = e % NT16;
+      int ci = (e / NT16) % CT16;
+      int tap = e / (NT16 * CT16);
+      if (co < Cout && ci < Cin) {
+        size_t o = ((size_t)co * Cin + ci) * ntap + tap;
+        grad[o] = accumulate ? grad[o] + s : s;
+      }
+    } else if (grad_b) {
+      int co = e - nw;
+      if (co < Cout) grad_b[co] = accumulate ? grad_b[co] + s : s;
     }
   }
 }
@@ -652,8 +672,8 @@ __global__ void __launch_bounds__(64 * PTH) conv_ws_bf16_kernel(ConvArgsH a, int
             for (int j = 0; j < 4; ++j) v[j] = apply_act(a.alpha * (acc[m][q][j] + bj[j]), a.act);
           }
           uint2 pk;
-          pk.x = (unsigned)zt_f2bf(v[0]) | ((unsigned)zt_f2bf(v[1]) << 16);
-          pk.y = (unsigned)zt_f2bf(v[2]) | ((unsigned)zt_f2bf(v[3]) << 16);
+          pk.x = zt_f2bf2(v[0], v[1]);
+          pk.y = zt_f2bf2(v[2], v[3]);
           *reinterpret_cast<uint2*>(st + (m * 16 + l15) * OP + q * 16 + l4 * 4) = pk;
         }
       }
@@ -785,6 +805,9 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
   for (int p = 0; p < PPW; ++p)
 #pragma unroll
     for (int q = 0; q < NT; ++q) acc[p][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NPART = 256 / (NT * 16);
+  const int bco = tid % (NT * 16), bpart = tid / (NT * 16);
+  float bsum = 0.f;
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int tx = tile % a.tilesX, ty = tile / a.tilesX;
@@ -827,6 +850,8 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
       *reinterpret_cast<uint4*>(zs + p * COP + c) = v;
     }
     __syncthreads();
+    if (bpart < NPART)
+      for (int p = bpart; p < HTH * HTW; p += NPART) bsum += zt_bf2f(zs[p * COP + bco]);
 #pragma unroll 1
     for (int r = 0; r < HTH; ++r) {
       zt_s16x8 bv[NT];
@@ -852,7 +877,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
       }
     }
   }
-  float* out = a.slab + (size_t)blockIdx.x * (KH * KW * CT * 16 * NT * 16);
+  float* out = a.slab + (size_t)blockIdx.x * (KH * KW * CT * 16 * NT * 16 + NT * 16);
   const int l4 = lane >> 4;
 #pragma unroll
   for (int pi = 0; pi < PPW; ++pi) {
@@ -865,6 +890,15 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
         for (int j = 0; j < 4; ++j)
           out[((size_t)tap * CT * 16 + cit * 16 + l4 * 4 + j) * (NT * 16) + q * 16 + l15] = acc[pi][q][j];
     }
+  }
+  __syncthreads();
+  float* fz = reinterpret_cast<float*>(zs);                 // HTH*HTW*COP bf16 >= NPART*NT16 floats
+  if (bpart < NPART) fz[bpart * (NT * 16) + bco] = bsum;
+  __syncthreads();
+  if (tid < NT * 16) {
+    float sum = 0.f;
+    for (int k = 0; k < NPART; ++k) sum += fz[k * (NT * 16) + tid];
+    out[KH * KW * CT * 16 * NT * 16 + tid] = sum;
   }
 }
 
@@ -952,7 +986,7 @@ extern "C" int zt_conv2d_nhwc_f32(const float* x, const float* x2, int csplit, i
 
 extern "C" int zt_conv2d_wgrad_nhwc_f32(const float* x, int ldx, const float* dz, int lddz, int H, int W, int Cin,
                                         int Cout, int KH, int KW, float* slab, size_t slab_bytes, float* grad_w,
-                                        int accumulate, hipStream_t stream) {
+                                        float* grad_b, int accumulate, hipStream_t stream) {
   ZT_REQUIRE(x && dz && slab && grad_w && ldx % 4 == 0 && lddz % 4 == 0);
   ZT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dz & 15) == 0);
   int CT = (Cin + 15) / 16, NT = (Cout + 15) / 16;
@@ -960,7 +994,7 @@ extern "C" int zt_conv2d_wgrad_nhwc_f32(const float* x, int ldx, const float* dz
   a.x = x; a.dz = dz; a.slab = slab; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.Cout = Cout; a.lddz = lddz;
   a.tilesX = zt_cdiv(W, WTW);
   a.ntiles = a.tilesX * zt_cdiv(H, WTH);
-  size_t per = (size_t)KH * KW * CT * 16 * NT * 16 * sizeof(float);
+  size_t per = ((size_t)KH * KW * CT * 16 * NT * 16 + NT * 16) * sizeof(float);
   int nblk = a.ntiles < 512 ? a.ntiles : 512;
   if ((size_t)nblk * per > slab_bytes) nblk = (int)(slab_bytes / per);
   ZT_REQUIRE(nblk >= 1);
@@ -968,9 +1002,9 @@ extern "C" int zt_conv2d_wgrad_nhwc_f32(const float* x, int ldx, const float* dz
   if (KH == 3 && KW == 3) rc = launch_wgrad<3, 3>(a, CT, NT, nblk, stream);
   else if (KH == 1 && KW == 1) rc = launch_wgrad<1, 1>(a, CT, NT, nblk, stream);
   if (rc) return rc;
-  int total = KH * KW * CT * 16 * NT * 16;
+  int total = KH * KW * CT * 16 * NT * 16 + NT * 16;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(zt_cdiv(total, 64)), dim3(256), 0, stream, (const float*)slab, nblk,
-                     KH * KW, CT * 16, NT * 16, grad_w, Cout, Cin, accumulate);
+                     KH * KW, CT * 16, NT * 16, grad_w, Cout, Cin, accumulate, grad_b);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
@@ -1052,8 +1086,8 @@ extern "C" int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, in
 }
 
 extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout,
-                                         int KH, int KW, float* slab, size_t slab_bytes, float* grad_w, int accumulate,
-                                         hipStream_t stream) {
+                                         int KH, int KW, float* slab, size_t slab_bytes, float* grad_w, float* grad_b,
+                                         int accumulate, hipStream_t stream) {
   ZT_REQUIRE(x && dz && slab && grad_w && ldx % 8 == 0 && lddz % 8 == 0);
   ZT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dz & 15) == 0);
   int CT = (Cin + 15) / 16, NT = (Cout + 15) / 16;
@@ -1062,7 +1096,7 @@ extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
   a.lddz = lddz;
   a.tilesX = zt_cdiv(W, HTW);
   a.ntiles = a.tilesX * zt_cdiv(H, HTH);
-  size_t per = (size_t)KH * KW * CT * 16 * NT * 16 * sizeof(float);
+  size_t per = ((size_t)KH * KW * CT * 16 * NT * 16 + NT * 16) * sizeof(float);
   int nblk = a.ntiles < 512 ? a.ntiles : 512;
   if ((size_t)nblk * per > slab_bytes) nblk = (int)(slab_bytes / per);
   ZT_REQUIRE(nblk >= 1);
@@ -1070,9 +1104,9 @@ extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
   if (KH == 3 && KW == 3) rc = launch_wgrad_h<3, 3>(a, CT, NT, nblk, stream);
   else if (KH == 1 && KW == 1) rc = launch_wgrad_h<1, 1>(a, CT, NT, nblk, stream);
   if (rc) return rc;
-  int total = KH * KW * CT * 16 * NT * 16;
+  int total = KH * KW * CT * 16 * NT * 16 + NT * 16;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(zt_cdiv(total, 64)), dim3(256), 0, stream, (const float*)slab, nblk, KH * KW,
-                     CT * 16, NT * 16, grad_w, Cout, Cin, accumulate);
+                     CT * 16, NT * 16, grad_w, Cout, Cin, accumulate, grad_b);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

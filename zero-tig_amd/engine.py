@@ -64,9 +64,10 @@ class Engine:
             return self.ops.conv2d_bf16(x, self.wd[wkey], bias, cout, k, k, pad, act, out_planar=out_planar, aux=aux, epi=epi)
         return self.ops.conv2d(x, self.wd[wkey], bias, cout, k, k, 1, pad, act, out_planar=out_planar, aux=aux, epi=epi)
 
-    def _wgrad(self, x, dz, cout, k, gname):
+    def _wgrad(self, x, dz, cout, k, pre):
+        """accumulate d loss / d weight and d loss / d bias (column sums of dz, same pass) of conv `pre`"""
         fn = self.ops.conv2d_wgrad_bf16 if self.dt else self.ops.conv2d_wgrad
-        fn(x, dz, cout, k, k, self.g[gname], accumulate=True)
+        fn(x, dz, cout, k, k, self.g[pre + ".weight"], accumulate=True, grad_b=self.g[pre + ".bias"])
 
     def _newa(self, *shape):
         return torch.empty(shape, dtype=self.adt, device=self.dev)
@@ -105,14 +106,11 @@ class Engine:
         [1,cin,H,W] gradient of the packed input when requested."""
         u, a1, a2, cin = self.sv[key]
         drv = CV(dr, 0, cout)
-        self._wgrad(a2, drv, cout, 1, pre + ".conv3.weight")
-        self._bias_grad(dr, cout, pre + ".conv3.bias")
+        self._wgrad(a2, drv, cout, 1, pre + ".conv3")
         dz2 = self._conv(drv, pre + ".conv3/T", None, 48, 1, None, aux=a2, epi=1)
-        self._wgrad(a1, dz2, 48, 3, pre + ".conv2.weight")
-        self._bias_grad(dz2, 48, pre + ".conv2.bias")
+        self._wgrad(a1, dz2, 48, 3, pre + ".conv2")
         dz1 = self._conv(dz2, pre + ".conv2/T", None, 48, 3, None, aux=a1, epi=1)
-        self._wgrad(CV(u, 0, cin), dz1, 48, 3, pre + ".conv1.weight")
-        self._bias_grad(dz1, 48, pre + ".conv1.bias")
+        self._wgrad(CV(u, 0, cin), dz1, 48, 3, pre + ".conv1")
         if want_input_grad:
             return self._conv(dz1, pre + ".conv1/T", None, cin, 3, None, out_planar=True)
         return None
@@ -149,22 +147,19 @@ class Engine:
         u, feats, zs, stats = self.sv["E"]
         H, W = feats[0].shape[1], feats[0].shape[2]
         dOv = CV(dO, 0, 3)
-        self._wgrad(feats[3], dOv, 3, 3, "enhance.out_conv.0.weight")
-        self._bias_grad(dO, 3, "enhance.out_conv.0.bias")
+        self._wgrad(feats[3], dOv, 3, 3, "enhance.out_conv.0")
         df = self._conv(dOv, "enhance.out_conv.0/T", None, 64, 3, None)
         for i in (2, 1, 0):
             sc, sh, mu, rs = stats[i]
             # eval-mode BN (the reference trains epochs >= 1 like this, train.py:138 / SURVEY A-14): running stats are constants
             dz = o.bn_relu_bwd(df, zs[i], sc, sh, mu, rs, g["enhance.conv.1.weight"], g["enhance.conv.1.bias"],
                                eval_mode=not self.training)
-            self._wgrad(feats[i], dz, 64, 3, "enhance.conv.0.weight")
-            self._bias_grad(dz, 64, "enhance.conv.0.bias")
+            self._wgrad(feats[i], dz, 64, 3, "enhance.conv.0")
             df = self._conv(dz, "enhance.conv.0/T", None, 64, 3, None, aux=df, epi=3)
         # through the in_conv ReLU: mask by the saved activation (epi 2 of a 1x1 identity is overkill -> dedicated op)
         dz0 = self._newa(1, H, W, 64)
         self.lib.call("zt_relu_mask_nhwc", df, self.dt, 64, feats[0], 64, dz0, 64, H * W, 64, self._stream())
-        self._wgrad(CV(u, 0, 9), dz0, 64, 3, "enhance.in_conv.0.weight")
-        self._bias_grad(dz0, 64, "enhance.in_conv.0.bias")
+        self._wgrad(CV(u, 0, 9), dz0, 64, 3, "enhance.in_conv.0")
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, inp, cache_fn=None, keep=True):

@@ -205,14 +205,14 @@ class Ops:
             self._slab[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         return self._slab[key]
 
-    def conv2d_wgrad(self, x, dz, Cout, KH, KW, grad_w, accumulate=False, slab=None):
+    def conv2d_wgrad(self, x, dz, Cout, KH, KW, grad_w, accumulate=False, slab=None, grad_b=None):
         """grad_w [Cout,Cin,KH,KW] (+)= wgrad of a stride-1 same conv; x, dz: CV/tensor NHWC (N == 1)."""
         x, dz = _cv(x), _cv(dz)
         assert x.N == 1 and (x.H, x.W) == (dz.H, dz.W) and dz.C >= Cout
         assert tuple(grad_w.shape) == (Cout, x.C, KH, KW) and grad_w.is_contiguous()
         slab = self.slab(x.t.device) if slab is None else slab
         self.lib.call("zt_conv2d_wgrad_nhwc_f32", x.ptr, x.ld, dz.ptr, dz.ld, x.H, x.W, x.C, Cout, KH, KW, slab,
-                      slab.numel() * 4, grad_w, int(accumulate), self._s(x.t))
+                      slab.numel() * 4, grad_w, grad_b, int(accumulate), self._s(x.t))
         return grad_w
 
     # ---- normalisation (zt_norm.hip) --------------------------------------------------------------------------
@@ -377,12 +377,12 @@ class Ops:
             prof["events"].append((e0, e1))
         return out
 
-    def conv2d_wgrad_bf16(self, x, dz, Cout, KH, KW, grad_w, accumulate=False, slab=None):
+    def conv2d_wgrad_bf16(self, x, dz, Cout, KH, KW, grad_w, accumulate=False, slab=None, grad_b=None):
         x, dz = _cv(x), _cv(dz)
         assert x.t.dtype == torch.bfloat16 and dz.t.dtype == torch.bfloat16
         assert x.N == 1 and (x.H, x.W) == (dz.H, dz.W) and dz.C >= Cout
         assert tuple(grad_w.shape) == (Cout, x.C, KH, KW) and grad_w.is_contiguous() and grad_w.dtype == torch.float32
         slab = self.slab(x.t.device) if slab is None else slab
         self.lib.call("zt_conv2d_wgrad_nhwc_bf16", x.ptr, x.ld, dz.ptr, dz.ld, x.H, x.W, x.C, Cout, KH, KW, slab, slab.numel() * 4,
-                      grad_w, int(accumulate), self._s(x.t))
+                      grad_w, grad_b, int(accumulate), self._s(x.t))
         return grad_w
