@@ -852,6 +852,17 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
     __syncthreads();
     if (bpart < NPART)
       for (int p = bpart; p < HTH * HTW; p += NPART) bsum += zt_bf2f(zs[p * COP + bco]);
+    // per-wave (tap, ci-tile) pairs: branch-free (a wave without a pair in the last round recomputes the final pair into an
+    // accumulator that is never written out), A fragments double-buffered and pinned ahead of the previous pair's MFMAs
+    int aoff[PPW];
+#pragma unroll
+    for (int pi = 0; pi < PPW; ++pi) {
+      int pr = wave + 4 * pi;
+      pr = pr < NPAIR ? pr : NPAIR - 1;
+      const int tap = pr / CT, cit = pr - tap * CT;
+      const int ky = tap / KW, kx = tap - ky * KW;
+      aoff[pi] = (ky * IC + kx + g8 + trq) * CIP + cit * 16 + trp;
+    }
 #pragma unroll 1
     for (int r = 0; r < HTH; ++r) {
       zt_s16x8 bv[NT];
@@ -861,20 +872,23 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
         zt_s16x4 hi = zt_lds_read_tr16(zs + (r * HTW + g8 + 4 + trq) * COP + q * 16 + trp);
         bv[q] = (zt_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
-#pragma unroll
-      for (int pi = 0; pi < PPW; ++pi) {
-        const int pr = wave + 4 * pi;
-        if (pr < NPAIR) {                    // wave-uniform
-          const int tap = pr / CT, cit = pr - tap * CT;
-          const int ky = tap / KW, kx = tap - ky * KW;
-          const zt_bf16* base = xs + ((r + ky) * IC + kx + g8 + trq) * CIP + cit * 16 + trp;
-          zt_s16x4 lo = zt_lds_read_tr16(base);
-          zt_s16x4 hi = zt_lds_read_tr16(base + 4 * CIP);
-          zt_s16x8 av = (zt_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-          for (int q = 0; q < NT; ++q) acc[pi][q] = zt_mfma_bf16(av, bv[q], acc[pi][q]);
+      const zt_bf16* xr = xs + r * IC * CIP;
+      zt_s16x4 alo[2], ahi[2];
+      alo[0] = zt_lds_read_tr16(xr + aoff[0]);
+      ahi[0] = zt_lds_read_tr16(xr + aoff[0] + 4 * CIP);
+      zt_static_for<0, PPW>([&](auto pi_c) {
+        constexpr int pi = decltype(pi_c)::value;
+        constexpr int cur = pi & 1;
+        if constexpr (pi + 1 < PPW) {
+          alo[cur ^ 1] = zt_lds_read_tr16(xr + aoff[pi + 1]);
+          ahi[cur ^ 1] = zt_lds_read_tr16(xr + aoff[pi + 1] + 4 * CIP);
         }
-      }
+        __builtin_amdgcn_sched_barrier(0);
+        zt_s16x8 av = (zt_s16x8){alo[cur][0], alo[cur][1], alo[cur][2], alo[cur][3], ahi[cur][0], ahi[cur][1], ahi[cur][2], ahi[cur][3]};
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[pi][q] = zt_mfma_bf16(av, bv[q], acc[pi][q]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
     }
   }
   float* out = a.slab + (size_t)blockIdx.x * (KH * KW * CT * 16 * NT * 16 + NT * 16);
