@@ -1111,7 +1111,9 @@ extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
   a.tilesX = zt_cdiv(W, HTW);
   a.ntiles = a.tilesX * zt_cdiv(H, HTH);
   size_t per = ((size_t)KH * KW * CT * 16 * NT * 16 + NT * 16) * sizeof(float);
-  int nblk = a.ntiles < 512 ? a.ntiles : 512;
+  int want = 512;
+  if (const char* e = getenv("ZT_WGRAD_BLOCKS")) want = atoi(e) > 0 ? atoi(e) : want;      // tuning hook
+  int nblk = a.ntiles < want ? a.ntiles : want;
   if ((size_t)nblk * per > slab_bytes) nblk = (int)(slab_bytes / per);
   ZT_REQUIRE(nblk >= 1);
   int rc = ZT_EINVAL;
