@@ -333,7 +333,7 @@ BF16_CONV = [(3, 48, 3, 8, "lrelu"), (48, 48, 3, 48, "lrelu"), (64, 64, 3, 64, "
              (48, 6, 1, 48, None), (9, 64, 3, 16, "relu"), (12, 48, 3, 16, None)]
 
 
-@pytest.mark.parametrize("variant", [2, 1], ids=["tiled", "ws"])
+@pytest.mark.parametrize("variant", [2, 1, 3], ids=["tiled", "ws", "pc"])
 @pytest.mark.parametrize("case", BF16_CONV, ids=lambda c: "c%d-%d_k%d" % c[:3])
 def test_conv_bf16(backend, case, variant):
     import torch.nn.functional as F
@@ -341,8 +341,10 @@ def test_conv_bf16(backend, case, variant):
     CV = import_module("zero-tig_amd.ops").CV
     ops, dev, _ = backend
     Cin, Cout, K, ld, act = case
+    if variant == 3 and not (K == 3 and Cout >= 48 and act in (None, "relu", "lrelu")):
+        pytest.skip("producer/consumer kernel covers the 3x3 48/64-cout layers")
     g = torch.Generator().manual_seed(Cin * 17 + Cout)
-    H, W = (19, 37) if variant == 1 else (7, 37)          # 19 rows: three 8-row tiles of the persistent kernel, ragged
+    H, W = (19, 37) if variant != 2 else (7, 37)          # 19 rows: ragged multiple of the persistent kernels' tile heights
     x = torch.randn(1, Cin, H, W, generator=g).bfloat16().float()
     w = (torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5)
     b = torch.randn(Cout, generator=g) * 0.1
@@ -369,6 +371,34 @@ def test_conv_bf16(backend, case, variant):
                              aux=_nhwc_bf16(aux, Cin).to(dev), epi=1, variant=variant)
         gotg = dx.float().cpu().permute(0, 3, 1, 2)
         assert float(((gotg - refg).abs() - refg.abs() * 2 ** -8).max()) < 2e-3
+
+
+@pytest.mark.parametrize("case", [(64, 64, "relu", 3), (48, 48, "lrelu", 0), (9, 64, "relu", 0)], ids=lambda c: "c%d-%d_epi%d" % (c[0], c[1], c[3]))
+def test_conv_bf16_pc_pipeline(backend, case):
+    """Producer/consumer persistent kernel with several tiles per workgroup (700 tiles on <= 256 workgroups): exercises the
+    double-buffered halo / staging hand-off between the I/O waves and the MFMA waves, ragged right and bottom edges."""
+    import torch.nn.functional as F
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    Cin, Cout, act, epi = case
+    g = torch.Generator().manual_seed(Cin + Cout)
+    H, W = 198, 421
+    x = torch.randn(1, Cin, H, W, generator=g).bfloat16().float()
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w.bfloat16().float(), b, padding=1)
+    ref = torch.relu(ref) if act == "relu" else F.leaky_relu(ref, 0.2)
+    aux = torch.randn(1, Cout, H, W, generator=g).bfloat16().float()
+    mag = ref.abs()
+    if epi == 3:
+        ref = ref + aux
+        mag = mag * 2 + ref.abs()       # the I/O waves add the residual to the bf16-staged conv output: that rounding does not cancel
+    ld = (Cin + 7) // 8 * 8
+    y = ops.conv2d_bf16(CV(_nhwc_bf16(x, ld).to(dev), 0, Cin), ops.repack_weight_bf16(w.to(dev)), b.to(dev), Cout, 3, 3, (1, 1), act,
+                        aux=_nhwc_bf16(aux, Cout).to(dev) if epi else None, epi=epi, variant=3)
+    got = y.float().cpu()[..., :Cout].permute(0, 3, 1, 2)
+    assert float(((got - ref).abs() - mag * 2 ** -8).max()) < 2e-3
 
 
 BF16_WGRAD = [(3, 48, 3, 8, 48), (48, 48, 3, 48, 48), (48, 3, 1, 48, 8), (9, 64, 3, 16, 64), (64, 64, 3, 64, 64), (64, 3, 3, 64, 8),

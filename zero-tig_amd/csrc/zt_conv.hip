@@ -773,6 +773,221 @@ int launch_conv_ws(ConvArgsH& a, int NT, int CCH, int pth, hipStream_t stream) {
 #undef ZT_WS
 }
 
+// ---- producer / consumer variant of the persistent kernel (3x3, stride 1, bf16 nhwc output): waves 0-3 only issue MFMAs
+// (one output row of a 4 x 32 tile each) and park their results in an LDS staging buffer; waves 4-5 only move data -- next
+// tile's halo global -> registers -> LDS, previous tile's staged outputs LDS -> global (16 B/lane, fused dgrad-mask / residual
+// epilogue).  Halo and staging are double-buffered, so ONE barrier per tile separates the stages and HBM reads, MFMA and HBM
+// writes of consecutive tiles overlap inside the workgroup.  To fit 160 KB every LDS image uses unpadded 128-byte rows with
+// the 16-byte chunk index XOR-swizzled by the row (pixel & 7, or (cout >> 1) & 7 for weights): conflict-free for every
+// ds_read_b128 lane group and every tap shift (brute-forced).
+constexpr int QTH = 4;
+
+template <int NT, int CCH>
+__global__ void __launch_bounds__(384) conv_pc_bf16_kernel(ConvArgsH a, int ntiles) {
+  constexpr int K = 3, IR = QTH + K - 1, IC = TW + K - 1;
+  constexpr int NCH = CCH * 4;                                 // 16-byte chunks per pixel actually used
+  constexpr int NPF = (IR * IC * NCH + 127) / 128;             // halo prefetch registers per I/O thread
+  constexpr int NOUT = (TW * NT * 2 + 63) / 64;                // staged 16-byte chunks per I/O lane per row
+  __shared__ __attribute__((aligned(16))) zt_bf16 ws[K * K * NT * 16 * 64];
+  __shared__ __attribute__((aligned(16))) zt_bf16 xs[2][IR * IC * 64];
+  __shared__ __attribute__((aligned(16))) zt_bf16 st[2][QTH * TW * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int co0 = blockIdx.y * (NT * 16);
+  const bool io = wave >= QTH;
+
+  // all six waves: weights once
+  for (int e = tid; e < K * K * NT * 16 * NCH; e += 384) {
+    int q = e % NCH, r = e / NCH;
+    int co = r % (NT * 16), tap = r / (NT * 16);
+    int c = q * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (c < a.ldk && co0 + co < a.CoutP) v = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.CoutP + co0 + co) * a.ldk + c);
+    *reinterpret_cast<uint4*>(ws + (tap * NT * 16 + co) * 64 + ((q ^ ((co >> 1) & 7)) * 8)) = v;
+  }
+
+  const int n_my = blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int iot = tid - QTH * 64;                              // 0..127 for the I/O threads
+  uint4 pf[NPF];
+  int pf_iy[NPF], pf_ix[NPF], pf_q[NPF];
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    int e = iot + i * 128;
+    int q = e % NCH, p = e / NCH;
+    pf_iy[i] = (io && e < IR * IC * NCH) ? p / IC : -100000;
+    pf_ix[i] = p % IC;
+    pf_q[i] = q;
+  }
+  auto load_halo = [&](int k) {
+    const int tile = blockIdx.x + k * gridDim.x;
+    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const int gy0 = ty * QTH - 1, gx0 = tx * TW - 1;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      const int gy = gy0 + pf_iy[i], gx = gx0 + pf_ix[i], c = pf_q[i] * 8;
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Cin) {
+        v = *reinterpret_cast<const uint4*>(a.x + ((size_t)gy * a.W + gx) * a.ldx + c);
+        if (c + 8 > a.Cin) {
+          zt_bf16 tmp[8];
+          __builtin_memcpy(tmp, &v, 16);
+          for (int j = 0; j < 8; ++j)
+            if (c + j >= a.Cin) tmp[j] = 0;
+          __builtin_memcpy(&v, tmp, 16);
+        }
+      }
+      pf[i] = v;
+    }
+  };
+  auto write_halo = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      if (pf_iy[i] >= 0) {
+        const int p = pf_iy[i] * IC + pf_ix[i];
+        *reinterpret_cast<uint4*>(&xs[buf][p * 64 + ((pf_q[i] ^ (p & 7)) * 8)]) = pf[i];
+      }
+    }
+  };
+  auto store_tile = [&](int k) {                               // I/O waves: staged outputs of tile k -> global
+    const int tile = blockIdx.x + k * gridDim.x;
+    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const int buf = k & 1;
+    for (int r = wave - QTH; r < QTH; r += 2) {                // two I/O waves, two rows each
+      const int oy = ty * QTH + r;
+      if (oy >= a.Ho) continue;
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) {
+        const int e = lane + i * 64;
+        const int p = e / (NT * 2), ch = e % (NT * 2);
+        const int ox = tx * TW + p, co = co0 + ch * 8;
+        if (e < TW * NT * 2 && ox < a.Wo && co < a.Cout) {
+          uint4 v = *reinterpret_cast<const uint4*>(&st[buf][(r * TW + p) * 64 + ((ch ^ (p & 7)) * 8)]);
+          const size_t pix = (size_t)oy * a.Wo + ox;
+          if (a.epi) {
+            uint4 u = *reinterpret_cast<const uint4*>(a.aux + pix * a.ldaux + co);
+            zt_bf16 tv[8], tu[8];
+            __builtin_memcpy(tv, &v, 16);
+            __builtin_memcpy(tu, &u, 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float fv = zt_bf2f(tv[j]), fu = zt_bf2f(tu[j]);
+              if (a.epi == 1) fv *= (fu > 0.f ? 1.f : 0.2f);
+              else if (a.epi == 2) fv *= (fu > 0.f ? 1.f : 0.f);
+              else fv += fu;
+              tv[j] = zt_f2bf(fv);
+            }
+            __builtin_memcpy(&v, tv, 16);
+          }
+          zt_bf16* dst = (zt_bf16*)a.y + pix * a.ldy + co;
+          if (co + 8 <= a.Cout) *reinterpret_cast<uint4*>(dst) = v;
+          else {
+            zt_bf16 tv[8];
+            __builtin_memcpy(tv, &v, 16);
+            for (int j = 0; j < 8 && co + j < a.Cout; ++j) dst[j] = tv[j];
+          }
+        }
+      }
+    }
+  };
+
+  // prologue: halo of the first tile into xs[0], second tile's halo in flight
+  if (io && n_my > 0) {
+    load_halo(0);
+    write_halo(0);
+    if (n_my > 1) load_halo(1);
+  }
+  __syncthreads();
+
+  const float slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.2f);     // none / ReLU / LeakyReLU(0.2) == max(v, slope*v)
+  float bj[NT][4];
+#pragma unroll
+  for (int q = 0; q < NT; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = co0 + q * 16 + l4 * 4 + j;
+      bj[q][j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
+
+  for (int k = 0; k <= n_my; ++k) {
+    if (!io) {
+      if (k < n_my) {
+        const zt_bf16* xb = xs[k & 1];
+        zt_f32x4 acc[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int q = 0; q < NT; ++q) acc[m][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int NSTEP = K * K * CCH;
+        zt_s16x8 av[2][2], bv[2][NT];
+#define ZT_LOADF(bufi, step)                                                                                          \
+  {                                                                                                                   \
+    constexpr int tap_ = (step) / CCH, kc_ = (step) % CCH, ky_ = tap_ / K, kx_ = tap_ % K;                            \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                                   \
+      const int p_ = (wave + ky_) * IC + m * 16 + l15 + kx_;                                                          \
+      av[bufi][m] = *reinterpret_cast<const zt_s16x8*>(xb + p_ * 64 + (((kc_ * 4 + l4) ^ (p_ & 7)) * 8));             \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < NT; ++q) bv[bufi][q] = *reinterpret_cast<const zt_s16x8*>(                  \
+        ws + (tap_ * NT * 16 + q * 16 + l15) * 64 + (((kc_ * 4 + l4) ^ ((l15 >> 1) & 7)) * 8));                       \
+  }
+        ZT_LOADF(0, 0)
+        zt_static_for<0, NSTEP>([&](auto step_c) {
+          constexpr int step = decltype(step_c)::value;
+          constexpr int cur = step & 1;
+          if constexpr (step + 1 < NSTEP) ZT_LOADF(cur ^ 1, step + 1)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(bv[cur][q], av[cur][m], acc[m][q]);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+#undef ZT_LOADF
+        zt_bf16* sb = &st[k & 1][wave * TW * 64];
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] = a.alpha * (acc[m][q][j] + bj[q][j]);
+              v[j] = fmaxf(v[j], slope * v[j]);
+            }
+            uint2 pk;
+            pk.x = zt_f2bf2(v[0], v[1]);
+            pk.y = zt_f2bf2(v[2], v[3]);
+            const int p = m * 16 + l15;
+            *reinterpret_cast<uint2*>(sb + p * 64 + (((q * 2 + (l4 >> 1)) ^ (p & 7)) * 8) + (l4 & 1) * 4) = pk;
+          }
+      }
+    } else {
+      if (k + 1 < n_my) write_halo((k + 1) & 1);
+      if (k + 2 < n_my) load_halo(k + 2);
+      if (k >= 1) store_tile(k - 1);
+    }
+    __syncthreads();
+  }
+}
+
+int launch_conv_pc(ConvArgsH& a, int NT, int CCH, hipStream_t stream) {
+  int c16 = (a.Cout + 15) / 16;
+  a.tilesY = zt_cdiv(a.Ho, QTH);
+  int ntiles = a.tilesX * a.tilesY;
+  int gx = ntiles < 256 ? ntiles : 256;
+  dim3 grid(gx, (c16 + NT - 1) / NT), block(384);
+#define ZT_PC(nt, cch) hipLaunchKernelGGL((conv_pc_bf16_kernel<nt, cch>), grid, block, 0, stream, a, ntiles); return 0
+  if (CCH == 1) {
+    if (NT == 3) { ZT_PC(3, 1); }
+    if (NT == 4) { ZT_PC(4, 1); }
+  } else {
+    if (NT == 3) { ZT_PC(3, 2); }
+    if (NT == 4) { ZT_PC(4, 2); }
+  }
+#undef ZT_PC
+  return ZT_EINVAL;
+}
+
 // ---- bf16 weight gradient.  K = pixels: the MFMA needs 8 consecutive PIXELS per lane for one channel, i.e. the
 // transpose of the NHWC tile; ds_read_b64_tr_b16 delivers exactly that from a [pixel][channel] LDS image, so staging is a
 // plain 16-byte copy and tap shifts are row shifts (alignment preserved).
@@ -1055,6 +1270,7 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   a.tilesY = zt_cdiv(a.Ho, TH);
   int c16 = (Cout + 15) / 16;
   int NT = c16 >= 4 ? ((c16 % 4 == 0) ? 4 : (c16 % 3 == 0 ? 3 : 4)) : c16;
+  const int NT0 = NT;
   // small feature maps (RAFT at 1/8 resolution): narrower tiles / fewer channels per workgroup so that >= ~2 workgroups per CU exist
   int MT = 2;
   long long wgs = (long long)zt_cdiv(a.Wo, 32) * a.tilesY * N * zt_cdiv(c16, NT);
@@ -1063,6 +1279,17 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   // full-resolution stride-1 layers of the enhancement nets: persistent weight-stationary kernel
   const bool ws_ok = N == 1 && stride == 1 && KH == KW && (KH == 1 || KH == 3) && padH == KH / 2 && padW == KW / 2 && Cin <= 64 && !x2;
   ZT_REQUIRE(variant != 1 || ws_ok);
+  // producer / consumer kernel: 3x3, bf16 nhwc output, simple activation, 48 or 64 output channels per workgroup
+  const bool pc_ok = ws_ok && KH == 3 && out_mode == 0 && act <= 2 && (NT0 == 3 || NT0 == 4);
+  ZT_REQUIRE(variant != 3 || pc_ok);
+  static const int pc_auto = getenv("ZT_CONV_PC") ? atoi(getenv("ZT_CONV_PC")) : 1;
+  if (pc_ok && (variant == 3 || (variant == 0 && pc_auto && (long long)zt_cdiv(a.Wo, TW) * zt_cdiv(a.Ho, QTH) >= 2048))) {
+    a.tilesX = zt_cdiv(a.Wo, TW);
+    int rcp = launch_conv_pc(a, NT0, Cin <= 32 ? 1 : 2, stream);
+    if (rcp) return rcp;
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+  }
   if (variant != 2 && ws_ok && (variant == 1 || (long long)zt_cdiv(a.Wo, TW) * zt_cdiv(a.Ho, 8) >= 1024)) {
     a.tilesX = zt_cdiv(a.Wo, TW);
     int CCH = Cin <= 32 ? 1 : 2;
