@@ -192,7 +192,7 @@ int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, int ldx, int 
                         int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout, int KH, int KW, int stride,
                         int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi, zt_stream_t stream);
 /* same, with the kernel variant pinned (tests / tuning): 0 auto, 1 persistent weight-stationary (stride 1, K in {1,3}, Cin <= 64, N == 1),
- * 2 tiled, 3 producer/consumer persistent (3x3, bf16 nhwc output, act in {none, ReLU, LeakyReLU}, 48 or 64 couts) */
+ * 2 tiled, 3 register-stationary persistent (3x3, bf16 nhwc output, act in {none, ReLU, LeakyReLU}, exactly 48 or 64 couts) */
 int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin, const void* w,
                                 int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout, int KH, int KW, int stride,
                                 int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi, int variant, zt_stream_t stream);

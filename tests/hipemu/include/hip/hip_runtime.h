@@ -256,6 +256,41 @@ static inline zt_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(zt_emu_bf16x8
   return d;
 }
 
+// v_mfma_f32_16x16x16_bf16: A[row=l&15][k=4*(l>>4)+j], B[k=4*(l>>4)+j][col=l&15], j = 0..3; D as 16x16x4
+static inline zt_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(zt_emu_s16x4 a, zt_emu_s16x4 b, zt_emu_f32x4 c, int, int, int) {
+  emu::Wave& w = emu::my_wave();
+  int l = emu::my_lane();
+  for (int j = 0; j < 4; ++j) {
+    float fa = zt_emu_bf16_to_f32(a[j]), fb = zt_emu_bf16_to_f32(b[j]);
+    memcpy(&w.buf[l][j], &fa, 4);
+    memcpy(&w.buf[l][8 + j], &fb, 4);
+  }
+  emu::wave_sync();
+  zt_emu_f32x4 d = c;
+  int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * (l >> 4) + r;
+    double acc = c[r];
+    for (int k = 0; k < 16; ++k) {
+      float av, bv;
+      memcpy(&av, &w.buf[(k >> 2) * 16 + row][k & 3], 4);
+      memcpy(&bv, &w.buf[(k >> 2) * 16 + col][8 + (k & 3)], 4);
+      acc += (double)av * (double)bv;
+    }
+    d[r] = (float)acc;
+  }
+  emu::wave_sync();
+  return d;
+}
+
+// global_load_lds_dwordx4 & co: lane copies `size` bytes from its global address to (wave-uniform LDS base) + size * lane
+static inline void zt_emu_glds(const void* g, void* lds_base, int size) {
+  memcpy((char*)lds_base + (size_t)size * emu::my_lane(), g, (size_t)size);
+}
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define ZT_OPAQUE(x) ((void)0)
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) zt_emu_glds((const void*)(g), (void*)(l), (size))
+
 // ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per 16-lane group, lane 4q+p supplies the address of row q, columns
 // 4p..4p+3; lane i receives column i of the 4 rows (row q in element q).
 static inline zt_emu_s16x4 zt_emu_ds_read_tr16(const void* p) {

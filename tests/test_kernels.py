@@ -333,7 +333,7 @@ BF16_CONV = [(3, 48, 3, 8, "lrelu"), (48, 48, 3, 48, "lrelu"), (64, 64, 3, 64, "
              (48, 6, 1, 48, None), (9, 64, 3, 16, "relu"), (12, 48, 3, 16, None)]
 
 
-@pytest.mark.parametrize("variant", [2, 1, 3], ids=["tiled", "ws", "pc"])
+@pytest.mark.parametrize("variant", [2, 1, 3], ids=["tiled", "ws", "rs"])
 @pytest.mark.parametrize("case", BF16_CONV, ids=lambda c: "c%d-%d_k%d" % c[:3])
 def test_conv_bf16(backend, case, variant):
     import torch.nn.functional as F
@@ -342,7 +342,7 @@ def test_conv_bf16(backend, case, variant):
     ops, dev, _ = backend
     Cin, Cout, K, ld, act = case
     if variant == 3 and not (K == 3 and Cout >= 48 and act in (None, "relu", "lrelu")):
-        pytest.skip("producer/consumer kernel covers the 3x3 48/64-cout layers")
+        pytest.skip("register-stationary kernel covers the 3x3 48/64-cout layers")
     g = torch.Generator().manual_seed(Cin * 17 + Cout)
     H, W = (19, 37) if variant != 2 else (7, 37)          # 19 rows: ragged multiple of the persistent kernels' tile heights
     x = torch.randn(1, Cin, H, W, generator=g).bfloat16().float()
@@ -373,17 +373,17 @@ def test_conv_bf16(backend, case, variant):
         assert float(((gotg - refg).abs() - refg.abs() * 2 ** -8).max()) < 2e-3
 
 
-@pytest.mark.parametrize("case", [(64, 64, "relu", 3), (48, 48, "lrelu", 0), (9, 64, "relu", 0)], ids=lambda c: "c%d-%d_epi%d" % (c[0], c[1], c[3]))
-def test_conv_bf16_pc_pipeline(backend, case):
-    """Producer/consumer persistent kernel with several tiles per workgroup (700 tiles on <= 256 workgroups): exercises the
-    double-buffered halo / staging hand-off between the I/O waves and the MFMA waves, ragged right and bottom edges."""
+@pytest.mark.parametrize("case", [(64, 64, "relu", 3), (64, 64, "relu", 0), (48, 48, "lrelu", 1), (9, 64, "relu", 0), (12, 48, "lrelu", 0), (3, 48, "lrelu", 2)], ids=lambda c: "c%d-%d_epi%d" % (c[0], c[1], c[3]))
+def test_conv_bf16_rs_pipeline(backend, case):
+    """Register-stationary persistent kernel with several tiles per workgroup (> 256 tiles): exercises the double-buffered halo
+    and output staging across tile iterations, ragged right and bottom edges, every channel-chunk instantiation."""
     import torch.nn.functional as F
     from importlib import import_module
     CV = import_module("zero-tig_amd.ops").CV
     ops, dev, _ = backend
     Cin, Cout, act, epi = case
     g = torch.Generator().manual_seed(Cin + Cout)
-    H, W = 198, 421
+    H, W = 291, 421          # 37 x 14 = 518 tiles of 8 x 32
     x = torch.randn(1, Cin, H, W, generator=g).bfloat16().float()
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
     b = torch.randn(Cout, generator=g) * 0.1
@@ -393,7 +393,9 @@ def test_conv_bf16_pc_pipeline(backend, case):
     mag = ref.abs()
     if epi == 3:
         ref = ref + aux
-        mag = mag * 2 + ref.abs()       # the I/O waves add the residual to the bf16-staged conv output: that rounding does not cancel
+        mag = mag * 2 + ref.abs()       # the residual is added to the bf16-staged conv output: that rounding does not cancel
+    elif epi:
+        ref = ref * torch.where(aux > 0, 1.0, 0.2 if epi == 1 else 0.0)
     ld = (Cin + 7) // 8 * 8
     y = ops.conv2d_bf16(CV(_nhwc_bf16(x, ld).to(dev), 0, Cin), ops.repack_weight_bf16(w.to(dev)), b.to(dev), Cout, 3, 3, (1, 1), act,
                         aux=_nhwc_bf16(aux, Cout).to(dev) if epi else None, epi=epi, variant=3)

@@ -31,9 +31,13 @@ def run(cin, cout, k, variant, epi=0, iters=10):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-names = {3: "producer/consumer", 1: "ws full", 2: "tiled", 17: "ws no-mfma", 18: "ws no-epilogue", 20: "ws no-prefetch", 19: "ws no-mfma no-epi", 23: "ws nothing but staging", 24: "ws full, no stagger"}
+names = {3: "register-stationary", 1: "ws full", 2: "tiled"}
 for (cin, cout, k) in ((64, 64, 3), (48, 48, 3)):
-    for v in (3, 1, 2):
+    for v in (3, 1):
         print("c%d->%d k%d  %-24s %8.1f us" % (cin, cout, k, names[v], run(cin, cout, k, v)), flush=True)
 print("c64->64 k3 ws full + residual epi %8.1f us" % run(64, 64, 3, 1, epi=3))
-print("c64->64 k3 pc + residual epi      %8.1f us" % run(64, 64, 3, 3, epi=3))
+print("c64->64 k3 rs + residual epi      %8.1f us" % run(64, 64, 3, 3, epi=3))
+print("c48->48 k3 rs + mask epi          %8.1f us" % run(48, 48, 3, 3, epi=1))
+for (cin, cout) in ((9, 64), (3, 48), (12, 48)):
+    for v in (3, 1):
+        print("c%d->%d k3  %-24s %8.1f us" % (cin, cout, names[v], run(cin, cout, 3, v)), flush=True)

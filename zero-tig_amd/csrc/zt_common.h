@@ -79,6 +79,11 @@ __device__ __forceinline__ float zt_bf2f(zt_bf16 h) {
   __builtin_memcpy(&f, &u, 4);
   return f;
 }
+__device__ __forceinline__ float zt_u2f(unsigned u) {
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
 __device__ __forceinline__ zt_bf16 zt_f2bf(float f) {                   // round to nearest even; hipcc emits v_cvt_pk_bf16_f32
   __bf16 h = (__bf16)f;
   zt_bf16 r;
@@ -132,6 +137,23 @@ __device__ __forceinline__ zt_f32x4 zt_mfma_bf16(zt_s16x8 a, zt_s16x8 b, zt_f32x
 __device__ __forceinline__ zt_s16x4 zt_lds_read_tr16(const zt_bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) zt_s16x4*)p);
 }
+
+// gfx950 LDS-DMA: every lane copies 16 bytes from its own global address to lds_wave_base + 16 * lane (no VGPR destination; the
+// destination is lane-linear, so a swizzled LDS image is produced by permuting the SOURCE addresses).  Completion is tracked
+// by vmcnt; __syncthreads() drains it.
+__device__ __forceinline__ void zt_glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// s_waitcnt vmcnt(0) only (gfx9 encoding: vmcnt = simm16[15:14|3:0], expcnt [6:4] and lgkmcnt [11:8] left at their maxima)
+__device__ __forceinline__ void zt_wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+// make a value opaque to the optimiser (keeps per-iteration address arithmetic from being hoisted out of a persistent loop and
+// spilled).  The host-side test emulator pre-defines it as a no-op.
+#ifndef ZT_OPAQUE
+#define ZT_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
 
 // compile-time counted loop: f(std::integral_constant<int, I>) for I in [B, E)
 template <int I>

@@ -773,218 +773,319 @@ int launch_conv_ws(ConvArgsH& a, int NT, int CCH, int pth, hipStream_t stream) {
 #undef ZT_WS
 }
 
-// ---- producer / consumer variant of the persistent kernel (3x3, stride 1, bf16 nhwc output): waves 0-3 only issue MFMAs
-// (one output row of a 4 x 32 tile each) and park their results in an LDS staging buffer; waves 4-5 only move data -- next
-// tile's halo global -> registers -> LDS, previous tile's staged outputs LDS -> global (16 B/lane, fused dgrad-mask / residual
-// epilogue).  Halo and staging are double-buffered, so ONE barrier per tile separates the stages and HBM reads, MFMA and HBM
-// writes of consecutive tiles overlap inside the workgroup.  To fit 160 KB every LDS image uses unpadded 128-byte rows with
-// the 16-byte chunk index XOR-swizzled by the row (pixel & 7, or (cout >> 1) & 7 for weights): conflict-free for every
-// ds_read_b128 lane group and every tap shift (brute-forced).
-constexpr int QTH = 4;
+// ---- register-stationary persistent kernel for the full-resolution 3x3 layers (stride 1, bf16 nhwc output, 48 or 64 couts).
+// The LDS-fed kernels above are LDS-bandwidth bound (0.75 fragment reads per MFMA against the 0.5 that 128 B/clk sustains), so
+// here the WEIGHTS LIVE IN REGISTERS for the whole launch (one persistent workgroup per CU, <= 162 VGPRs of A fragments per
+// wave) and LDS only carries pixels: a wave owns two adjacent output rows, so every pixel fragment it reads from the 4 halo
+// rows feeds both rows (ky and ky-1) -- 0.17-0.33 reads per MFMA.  What LDS capacity that frees goes to double-buffering the
+// halo (next tile's global loads fly during this tile's MFMAs and are written to the other buffer at its end) and the output
+// staging (tile k-1's 16-byte global stores, with the fused mask / residual epilogue, are issued inside tile k's MFMA loop).
+// One barrier per tile.  128-byte pixel rows are XOR-swizzled by (halo column & 7): conflict-free ds_read_b128 for every tap.
+// Channel tails use the K=16 MFMA (48 = 32 + 16, and the thin 3/9/12-channel inputs are a single K=16 chunk).
+constexpr int RTH = 8;
+__device__ const uint4 zt_zero_chunk = {0u, 0u, 0u, 0u};        // LDS-DMA source of the halo's out-of-image pixels
 
-template <int NT, int CCH>
-__global__ void __launch_bounds__(384) conv_pc_bf16_kernel(ConvArgsH a, int ntiles) {
-  constexpr int K = 3, IR = QTH + K - 1, IC = TW + K - 1;
-  constexpr int NCH = CCH * 4;                                 // 16-byte chunks per pixel actually used
-  constexpr int NPF = (IR * IC * NCH + 127) / 128;             // halo prefetch registers per I/O thread
-  constexpr int NOUT = (TW * NT * 2 + 63) / 64;                // staged 16-byte chunks per I/O lane per row
-  __shared__ __attribute__((aligned(16))) zt_bf16 ws[K * K * NT * 16 * 64];
-  __shared__ __attribute__((aligned(16))) zt_bf16 xs[2][IR * IC * 64];
-  __shared__ __attribute__((aligned(16))) zt_bf16 st[2][QTH * TW * 64];
+__device__ __forceinline__ zt_f32x4 zt_mfma_bf16_k16(zt_s16x4 a, zt_s16x4 b, zt_f32x4 c) {
+  // D = A(16x16) * B(16x16) + C: lane l holds A[row l&15][k = 4(l>>4)+j], B[k = 4(l>>4)+j][col l&15], j = 0..3
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
+// wave w of 8: row pair w >> 1; COSPLIT: couts [NQ*16*(w&1), +NQ*16) of 2*NQ*16, both 16-pixel halves (NM == 2)
+//                               else   : all NQ*16 couts, 16-pixel half (w & 1) (NM == 1)
+template <int NQ, int NM, bool COSPLIT, int C32, int C16, bool EPI>
+__global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntiles) {
+  constexpr int IR = RTH + 2, IC = TW + 2;
+  constexpr int KC = C32 * 32 + C16 * 16;                       // input channels staged per pixel
+  constexpr int PE = KC > 32 ? 64 : (KC > 16 ? 32 : 16);        // LDS elements per pixel; only the 128-byte rows need the swizzle
+  constexpr bool SWZ = PE == 64;
+  constexpr int NCHK = PE / 8;                                  // 16-byte chunks per pixel
+  constexpr bool GLDS = PE == 64;                               // full 128-byte rows go global -> LDS by DMA: no staging registers
+  constexpr int NPF = GLDS ? 1 : (IR * IC * NCHK + 511) / 512;
+  constexpr int NGL = (IR * IC * 8 + 511) / 512;                // LDS-DMA wave-instructions per wave and tile
+  constexpr int CW = (COSPLIT ? 2 : 1) * NQ * 16;               // couts of the layer (== a.Cout)
+  constexpr int CH8 = CW / 8;
+  constexpr bool SWZO = CW == 64;
+  constexpr int NOUT = RTH * TW * CH8 / 512;
+  static_assert(RTH * TW * CH8 % 512 == 0 && 512 % NCHK == 0, "tile geometry");
+  __shared__ __attribute__((aligned(16))) zt_bf16 xs[2][IR * IC * PE];
+  __shared__ __attribute__((aligned(16))) zt_bf16 st[2][RTH * TW * CW];
+  __shared__ float bias_s[CW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int co0 = blockIdx.y * (NT * 16);
-  const bool io = wave >= QTH;
+  const int rp = wave >> 1, sel = wave & 1;
+  const int q0 = COSPLIT ? sel * NQ : 0, m0 = COSPLIT ? 0 : sel;
 
-  // all six waves: weights once
-  for (int e = tid; e < K * K * NT * 16 * NCH; e += 384) {
-    int q = e % NCH, r = e / NCH;
-    int co = r % (NT * 16), tap = r / (NT * 16);
-    int c = q * 8;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (c < a.ldk && co0 + co < a.CoutP) v = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.CoutP + co0 + co) * a.ldk + c);
-    *reinterpret_cast<uint4*>(ws + (tap * NT * 16 + co) * 64 + ((q ^ ((co >> 1) & 7)) * 8)) = v;
-  }
+  if (tid < CW) bias_s[tid] = a.bias ? a.bias[tid] : 0.f;
+
+  // A fragments: weights [tap][CoutP][ldk], this wave's couts, all taps and channel chunks -- resident for the whole launch
+  zt_s16x8 w32[9][C32 > 0 ? C32 : 1][NQ];
+  zt_s16x4 w16[9][NQ];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const zt_bf16* wr = a.w + ((size_t)tap * a.CoutP + (q0 + q) * 16 + l15) * a.ldk;
+#pragma unroll
+      for (int c = 0; c < C32; ++c) {
+        const int kk = c * 32 + l4 * 8;
+        w32[tap][c][q] = kk < a.ldk ? *reinterpret_cast<const zt_s16x8*>(wr + kk) : (zt_s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+      if (C16) {
+        const int kk = C32 * 32 + l4 * 4;
+        w16[tap][q] = kk < a.ldk ? *reinterpret_cast<const zt_s16x4*>(wr + kk) : (zt_s16x4){0, 0, 0, 0};
+      }
+    }
 
   const int n_my = blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const int iot = tid - QTH * 64;                              // 0..127 for the I/O threads
+
+  // halo slot e = tid + 512 i -> pixel e / NCHK (row-major in the IR x IC halo), chunk e % NCHK == tid % NCHK for every i
   uint4 pf[NPF];
-  int pf_iy[NPF], pf_ix[NPF], pf_q[NPF];
+  const int hq = tid & (NCHK - 1);
+  const int hq8 = hq * 8 + 8 <= a.ldx ? hq * 8 : a.ldx - 8;     // never read past the pixel's channels; masked below
+  // LDS-DMA form: wave-instruction (8 i + wave) fills positions [64 (8 i + wave), +64) of the linear image; position e holds
+  // pixel e / 8, logical chunk (e % 8) ^ (column & 7) -- the swizzle is applied to the source address.  Needs Cin % 8 == 0.
+  auto glds_halo = [&](int k) {
+    const int tile = blockIdx.x + k * gridDim.x;
+    const int gy0 = (tile / a.tilesX) * RTH - 1, gx0 = (tile % a.tilesX) * TW - 1;
+    zt_bf16* xb = xs[k & 1];
+    int ln = lane;
+    ZT_OPAQUE(ln);                                              // recompute the slot geometry per tile instead of keeping it in registers
 #pragma unroll
-  for (int i = 0; i < NPF; ++i) {
-    int e = iot + i * 128;
-    int q = e % NCH, p = e / NCH;
-    pf_iy[i] = (io && e < IR * IC * NCH) ? p / IC : -100000;
-    pf_ix[i] = p % IC;
-    pf_q[i] = q;
-  }
+    for (int i = 0; i < NGL; ++i) {
+      const int e = (i * 8 + wave) * 64 + ln;
+      const int p = e >> 3, col = p % IC;
+      const int cj = (e & 7) ^ (col & 7);
+      const int gy = gy0 + p / IC, gx = gx0 + col;
+      const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && cj * 8 < a.Cin;
+      const int gyc = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+      const int cc = cj * 8 + 8 <= a.ldx ? cj * 8 : 0;
+      const zt_bf16* s1 = a.x + (unsigned)((gyc * a.W + gxc) * a.ldx + cc);
+      const void* src = in ? (const void*)s1 : (const void*)&zt_zero_chunk;
+      if (i * 512 + 511 < IR * IC * 8 || e < IR * IC * 8) zt_glds16(src, xb + (i * 8 + wave) * 512);
+    }
+  };
   auto load_halo = [&](int k) {
+    if constexpr (GLDS) {
+      glds_halo(k);
+      return;
+    }
     const int tile = blockIdx.x + k * gridDim.x;
-    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
-    const int gy0 = ty * QTH - 1, gx0 = tx * TW - 1;
+    const int gy0 = (tile / a.tilesX) * RTH - 1, gx0 = (tile % a.tilesX) * TW - 1;
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      const int gy = gy0 + pf_iy[i], gx = gx0 + pf_ix[i], c = pf_q[i] * 8;
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Cin) {
-        v = *reinterpret_cast<const uint4*>(a.x + ((size_t)gy * a.W + gx) * a.ldx + c);
-        if (c + 8 > a.Cin) {
-          zt_bf16 tmp[8];
-          __builtin_memcpy(tmp, &v, 16);
-          for (int j = 0; j < 8; ++j)
-            if (c + j >= a.Cin) tmp[j] = 0;
-          __builtin_memcpy(&v, tmp, 16);
-        }
-      }
-      pf[i] = v;
+      const int p = (tid + i * 512) / NCHK;
+      int gy = gy0 + p / IC, gx = gx0 + p % IC;                 // out-of-image slots read a clamped address, zeroed when written
+      gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+      gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+      pf[i] = *reinterpret_cast<const uint4*>(a.x + (unsigned)((gy * a.W + gx) * a.ldx + hq8));
     }
   };
-  auto write_halo = [&](int buf) {
+  auto write_halo = [&](int k) {
+    if constexpr (GLDS) return;
+    const int tile = blockIdx.x + k * gridDim.x;
+    const int gy0 = (tile / a.tilesX) * RTH - 1, gx0 = (tile % a.tilesX) * TW - 1;
+    const int nv = a.Cin - hq * 8;                              // valid channels of this thread's chunk: padding lanes are not trusted
+    const unsigned k0 = nv >= 2 ? ~0u : (nv == 1 ? 0xFFFFu : 0u), k1 = nv >= 4 ? ~0u : (nv == 3 ? 0xFFFFu : 0u);
+    const unsigned k2 = nv >= 6 ? ~0u : (nv == 5 ? 0xFFFFu : 0u), k3 = nv >= 8 ? ~0u : (nv == 7 ? 0xFFFFu : 0u);
+    zt_bf16* xb = xs[k & 1];
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      if (pf_iy[i] >= 0) {
-        const int p = pf_iy[i] * IC + pf_ix[i];
-        *reinterpret_cast<uint4*>(&xs[buf][p * 64 + ((pf_q[i] ^ (p & 7)) * 8)]) = pf[i];
-      }
-    }
-  };
-  auto store_tile = [&](int k) {                               // I/O waves: staged outputs of tile k -> global
-    const int tile = blockIdx.x + k * gridDim.x;
-    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
-    const int buf = k & 1;
-    for (int r = wave - QTH; r < QTH; r += 2) {                // two I/O waves, two rows each
-      const int oy = ty * QTH + r;
-      if (oy >= a.Ho) continue;
-#pragma unroll
-      for (int i = 0; i < NOUT; ++i) {
-        const int e = lane + i * 64;
-        const int p = e / (NT * 2), ch = e % (NT * 2);
-        const int ox = tx * TW + p, co = co0 + ch * 8;
-        if (e < TW * NT * 2 && ox < a.Wo && co < a.Cout) {
-          uint4 v = *reinterpret_cast<const uint4*>(&st[buf][(r * TW + p) * 64 + ((ch ^ (p & 7)) * 8)]);
-          const size_t pix = (size_t)oy * a.Wo + ox;
-          if (a.epi) {
-            uint4 u = *reinterpret_cast<const uint4*>(a.aux + pix * a.ldaux + co);
-            zt_bf16 tv[8], tu[8];
-            __builtin_memcpy(tv, &v, 16);
-            __builtin_memcpy(tu, &u, 16);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float fv = zt_bf2f(tv[j]), fu = zt_bf2f(tu[j]);
-              if (a.epi == 1) fv *= (fu > 0.f ? 1.f : 0.2f);
-              else if (a.epi == 2) fv *= (fu > 0.f ? 1.f : 0.f);
-              else fv += fu;
-              tv[j] = zt_f2bf(fv);
-            }
-            __builtin_memcpy(&v, tv, 16);
-          }
-          zt_bf16* dst = (zt_bf16*)a.y + pix * a.ldy + co;
-          if (co + 8 <= a.Cout) *reinterpret_cast<uint4*>(dst) = v;
-          else {
-            zt_bf16 tv[8];
-            __builtin_memcpy(tv, &v, 16);
-            for (int j = 0; j < 8 && co + j < a.Cout; ++j) dst[j] = tv[j];
-          }
-        }
-      }
+      const int e = tid + i * 512, p = e / NCHK, col = p % IC;
+      const int gy = gy0 + p / IC, gx = gx0 + col;
+      const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      uint4 v = pf[i];
+      v.x = in ? (v.x & k0) : 0u;
+      v.y = in ? (v.y & k1) : 0u;
+      v.z = in ? (v.z & k2) : 0u;
+      v.w = in ? (v.w & k3) : 0u;
+      if (e < IR * IC * NCHK) *reinterpret_cast<uint4*>(xb + p * PE + ((SWZ ? (hq ^ (col & 7)) : hq) * 8)) = v;
     }
   };
 
-  // prologue: halo of the first tile into xs[0], second tile's halo in flight
-  if (io && n_my > 0) {
+  // staged outputs of tile k -> global: chunk e = tid + 512 i -> pixel e / CH8 of the 8 x 32 tile, couts 8 (e % CH8)..+8.
+  // EPI: the aux tile (activation mask / residual) is DMA'd into the staging buffer that is idle during this tile's MFMA loop;
+  // chunk e is fetched by the very lane that consumes it (e = 64 (8 i + wave) + lane), so only that lane's vmcnt matters.
+  auto glds_aux = [&](int k, int buf) {
+    const int tile = blockIdx.x + k * gridDim.x;
+    const int oy0 = (tile / a.tilesX) * RTH, ox0 = (tile % a.tilesX) * TW;
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+      const int e = tid + i * 512, pl = e / CH8, ch = e % CH8;
+      int oy = oy0 + pl / TW, ox = ox0 + pl % TW;
+      oy = oy >= a.Ho ? a.Ho - 1 : oy;
+      ox = ox >= a.Wo ? a.Wo - 1 : ox;
+      zt_glds16(a.aux + (unsigned)((oy * a.Wo + ox) * a.ldaux + ch * 8), st[buf] + (i * 8 + wave) * 512);
+    }
+  };
+  auto store_tile = [&](int k) {
+    const int tile = blockIdx.x + k * gridDim.x;
+    const int oy0 = (tile / a.tilesX) * RTH, ox0 = (tile % a.tilesX) * TW;
+    const zt_bf16* sb = st[k & 1];
+    const zt_bf16* ab = st[(k + 1) & 1];
+    const float neg = a.epi == 1 ? 0.2f : 0.f;
+    if (EPI) zt_wait_vmcnt0();                                  // this lane's aux DMA has landed
+    uint4 v[NOUT];
+    if (!EPI) {                                                 // EPI runs mid-loop with every accumulator live: one chunk at a time
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) {
+        const int e = tid + i * 512, pl = e / CH8, ch = e % CH8;
+        v[i] = *reinterpret_cast<const uint4*>(sb + pl * CW + ((SWZO ? (ch ^ (pl & 7)) : ch) * 8));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+      const int e = tid + i * 512, pl = e / CH8, ch = e % CH8;
+      const int oy = oy0 + pl / TW, ox = ox0 + pl % TW;
+      uint4 o;
+      if (EPI) {
+        o = *reinterpret_cast<const uint4*>(sb + pl * CW + ((SWZO ? (ch ^ (pl & 7)) : ch) * 8));
+        const uint4 u = *reinterpret_cast<const uint4*>(ab + e * 8);
+        const unsigned vv[4] = {o.x, o.y, o.z, o.w}, uu[4] = {u.x, u.y, u.z, u.w};
+        unsigned oo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float f0 = zt_u2f(vv[j] << 16), f1 = zt_u2f(vv[j] & 0xFFFF0000u);
+          const float g0 = zt_u2f(uu[j] << 16), g1 = zt_u2f(uu[j] & 0xFFFF0000u);
+          if (a.epi == 3) { f0 += g0; f1 += g1; }
+          else { f0 *= (g0 > 0.f ? 1.f : neg); f1 *= (g1 > 0.f ? 1.f : neg); }
+          oo[j] = zt_f2bf2(f0, f1);
+        }
+        o = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+        __builtin_amdgcn_sched_barrier(0);                      // keep the chunks sequential (register pressure)
+      } else {
+        o = v[i];
+      }
+      if (oy < a.Ho && ox < a.Wo) *reinterpret_cast<uint4*>((zt_bf16*)a.y + (unsigned)((oy * a.Wo + ox) * a.ldy + ch * 8)) = o;
+    }
+  };
+
+  if (n_my > 0) {
     load_halo(0);
     write_halo(0);
-    if (n_my > 1) load_halo(1);
   }
   __syncthreads();
 
   const float slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.2f);     // none / ReLU / LeakyReLU(0.2) == max(v, slope*v)
-  float bj[NT][4];
+  // lane part of the pixel fragment address for kx = 0..2 (halo row and 16-pixel half are immediate offsets)
+  int xoff32[3][C32 > 0 ? C32 : 1], xoff16[3];
 #pragma unroll
-  for (int q = 0; q < NT; ++q)
+  for (int kx = 0; kx < 3; ++kx) {
+    const int col = l15 + kx;                                   // + 16 m: does not change col & 7
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int co = co0 + q * 16 + l4 * 4 + j;
-      bj[q][j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
-    }
-
-  for (int k = 0; k <= n_my; ++k) {
-    if (!io) {
-      if (k < n_my) {
-        const zt_bf16* xb = xs[k & 1];
-        zt_f32x4 acc[2][NT];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int q = 0; q < NT; ++q) acc[m][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
-        constexpr int NSTEP = K * K * CCH;
-        zt_s16x8 av[2][2], bv[2][NT];
-#define ZT_LOADF(bufi, step)                                                                                          \
-  {                                                                                                                   \
-    constexpr int tap_ = (step) / CCH, kc_ = (step) % CCH, ky_ = tap_ / K, kx_ = tap_ % K;                            \
-    _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                                   \
-      const int p_ = (wave + ky_) * IC + m * 16 + l15 + kx_;                                                          \
-      av[bufi][m] = *reinterpret_cast<const zt_s16x8*>(xb + p_ * 64 + (((kc_ * 4 + l4) ^ (p_ & 7)) * 8));             \
-    }                                                                                                                 \
-    _Pragma("unroll") for (int q = 0; q < NT; ++q) bv[bufi][q] = *reinterpret_cast<const zt_s16x8*>(                  \
-        ws + (tap_ * NT * 16 + q * 16 + l15) * 64 + (((kc_ * 4 + l4) ^ ((l15 >> 1) & 7)) * 8));                       \
+    for (int c = 0; c < C32; ++c) xoff32[kx][c] = col * PE + (SWZ ? (((c * 4 + l4) ^ (col & 7)) * 8) : (c * 32 + l4 * 8));
+    xoff16[kx] = col * PE + (SWZ ? (((C32 * 4 + (l4 >> 1)) ^ (col & 7)) * 8 + (l4 & 1) * 4) : (C32 * 32 + l4 * 4));
   }
-        ZT_LOADF(0, 0)
-        zt_static_for<0, NSTEP>([&](auto step_c) {
-          constexpr int step = decltype(step_c)::value;
-          constexpr int cur = step & 1;
-          if constexpr (step + 1 < NSTEP) ZT_LOADF(cur ^ 1, step + 1)
-          __builtin_amdgcn_sched_barrier(0);
+
+  for (int k = 0; k < n_my; ++k) {
+    const zt_bf16* xb = xs[k & 1] + ((2 * rp) * IC + m0 * 16) * PE;
+    zt_f32x4 acc[2][NM][NQ];
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(bv[cur][q], av[cur][m], acc[m][q]);
-          __builtin_amdgcn_sched_barrier(0);
-        });
-#undef ZT_LOADF
-        zt_bf16* sb = &st[k & 1][wave * TW * 64];
+      for (int m = 0; m < NM; ++m)
 #pragma unroll
-        for (int q = 0; q < NT; ++q)
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              v[j] = a.alpha * (acc[m][q][j] + bj[q][j]);
-              v[j] = fmaxf(v[j], slope * v[j]);
-            }
-            uint2 pk;
-            pk.x = zt_f2bf2(v[0], v[1]);
-            pk.y = zt_f2bf2(v[2], v[3]);
-            const int p = m * 16 + l15;
-            *reinterpret_cast<uint2*>(sb + p * 64 + (((q * 2 + (l4 >> 1)) ^ (p & 7)) * 8) + (l4 & 1) * 4) = pk;
-          }
-      }
+        for (int q = 0; q < NQ; ++q) acc[r][m][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (EPI) {
+      if (k >= 1) glds_aux(k - 1, k & 1);
+      if (k + 1 < n_my) load_halo(k + 1);
     } else {
-      if (k + 1 < n_my) write_halo((k + 1) & 1);
-      if (k + 2 < n_my) load_halo(k + 2);
+      if (k + 1 < n_my) load_halo(k + 1);
       if (k >= 1) store_tile(k - 1);
     }
+
+    // steps: halo row h (0..3) x kx x channel chunk; each step's fragments serve output rows r with ky = h - r in [0, 2]
+    constexpr int NCK = C32 + C16;
+    constexpr int NSTEP = 4 * 3 * NCK;
+    zt_s16x8 xa[2][NM];
+    zt_s16x4 xt[2][NM];
+#define ZT_LOADX(bufi, step)                                                                                          \
+  {                                                                                                                   \
+    constexpr int h_ = (step) / (3 * NCK), kx_ = ((step) / NCK) % 3, c_ = (step) % NCK;                               \
+    _Pragma("unroll") for (int m = 0; m < NM; ++m) {                                                                  \
+      if constexpr (c_ < C32) xa[bufi][m] = *reinterpret_cast<const zt_s16x8*>(xb + (h_ * IC + m * 16) * PE + xoff32[kx_][c_ < C32 ? c_ : 0]); \
+      else xt[bufi][m] = *reinterpret_cast<const zt_s16x4*>(xb + (h_ * IC + m * 16) * PE + xoff16[kx_]);              \
+    }                                                                                                                 \
+  }
+    ZT_LOADX(0, 0)
+    zt_static_for<0, NSTEP>([&](auto step_c) {
+      constexpr int step = decltype(step_c)::value;
+      constexpr int cur = step & 1;
+      constexpr int h = step / (3 * NCK), kx = (step / NCK) % 3, c = step % NCK;
+      if constexpr (step + 1 < NSTEP) ZT_LOADX(cur ^ 1, step + 1)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int ky = h - r;
+        if (ky >= 0 && ky <= 2) {
+#pragma unroll
+          for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+              if constexpr (c < C32) acc[r][m][q] = zt_mfma_bf16(w32[ky * 3 + kx][c < C32 ? c : 0][q], xa[cur][m], acc[r][m][q]);
+              else acc[r][m][q] = zt_mfma_bf16_k16(w16[ky * 3 + kx][q], xt[cur][m], acc[r][m][q]);
+            }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (EPI && step == NSTEP / 2 - 1) {             // aux has had half of the loop to arrive
+        if (k >= 1) store_tile(k - 1);
+        __syncthreads();                                        // aux consumed: the rest of the loop may end in staging writes to that buffer
+      }
+    });
+#undef ZT_LOADX
+    if (k + 1 < n_my) write_halo(k + 1);
+
+    // accumulators -> staging (bias, alpha, activation, bf16): lane holds couts 4 l4 .. +3 of 16-cout block q for pixel l15
+    zt_bf16* sb = st[k & 1];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int cb = (q0 + q) * 16 + l4 * 4;
+          const float4 bq = *reinterpret_cast<const float4*>(&bias_s[cb]);
+          const float bj[4] = {bq.x, bq.y, bq.z, bq.w};
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = a.alpha * (acc[r][m][q][j] + bj[j]);
+            v[j] = fmaxf(v[j], slope * v[j]);
+          }
+          uint2 pk;
+          pk.x = zt_f2bf2(v[0], v[1]);
+          pk.y = zt_f2bf2(v[2], v[3]);
+          const int pl = (2 * rp + r) * TW + (m0 + m) * 16 + l15;
+          const int ch = cb >> 3;
+          *reinterpret_cast<uint2*>(sb + pl * CW + ((SWZO ? (ch ^ (pl & 7)) : ch) * 8) + (cb & 4)) = pk;
+        }
     __syncthreads();
+  }
+  if (n_my > 0) {
+    if (EPI) glds_aux(n_my - 1, n_my & 1);
+    store_tile(n_my - 1);
   }
 }
 
-int launch_conv_pc(ConvArgsH& a, int NT, int CCH, hipStream_t stream) {
-  int c16 = (a.Cout + 15) / 16;
-  a.tilesY = zt_cdiv(a.Ho, QTH);
-  int ntiles = a.tilesX * a.tilesY;
-  int gx = ntiles < 256 ? ntiles : 256;
-  dim3 grid(gx, (c16 + NT - 1) / NT), block(384);
-#define ZT_PC(nt, cch) hipLaunchKernelGGL((conv_pc_bf16_kernel<nt, cch>), grid, block, 0, stream, a, ntiles); return 0
-  if (CCH == 1) {
-    if (NT == 3) { ZT_PC(3, 1); }
-    if (NT == 4) { ZT_PC(4, 1); }
-  } else {
-    if (NT == 3) { ZT_PC(3, 2); }
-    if (NT == 4) { ZT_PC(4, 2); }
+int launch_conv_rs(ConvArgsH& a, hipStream_t stream) {
+  a.tilesX = zt_cdiv(a.Wo, TW);
+  a.tilesY = zt_cdiv(a.Ho, RTH);
+  const int ntiles = a.tilesX * a.tilesY;
+  dim3 grid(ntiles < 256 ? ntiles : 256), block(512);
+  const int kc = a.Cin <= 16 ? 0 : (a.Cin > 48 ? 2 : 1);       // 0: one K=16 chunk, 1: 32 + 16, 2: 32 + 32
+#define ZT_RS(nq, nm, cs, c32, c16)                                                                                          \
+  {                                                                                                                          \
+    if (a.epi) hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, true>), grid, block, 0, stream, a, ntiles);      \
+    else hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, false>), grid, block, 0, stream, a, ntiles);           \
+    return 0;                                                                                                                \
   }
-#undef ZT_PC
+  if (a.Cout == 64 && kc == 2) ZT_RS(2, 2, true, 2, 0)
+  if (a.Cout == 64 && kc == 0) ZT_RS(2, 2, true, 0, 1)
+  if (a.Cout == 48 && kc == 1) ZT_RS(3, 1, false, 1, 1)
+  if (a.Cout == 48 && kc == 0) ZT_RS(3, 1, false, 0, 1)
+#undef ZT_RS
   return ZT_EINVAL;
 }
 
@@ -1270,7 +1371,6 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   a.tilesY = zt_cdiv(a.Ho, TH);
   int c16 = (Cout + 15) / 16;
   int NT = c16 >= 4 ? ((c16 % 4 == 0) ? 4 : (c16 % 3 == 0 ? 3 : 4)) : c16;
-  const int NT0 = NT;
   // small feature maps (RAFT at 1/8 resolution): narrower tiles / fewer channels per workgroup so that >= ~2 workgroups per CU exist
   int MT = 2;
   long long wgs = (long long)zt_cdiv(a.Wo, 32) * a.tilesY * N * zt_cdiv(c16, NT);
@@ -1279,13 +1379,14 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   // full-resolution stride-1 layers of the enhancement nets: persistent weight-stationary kernel
   const bool ws_ok = N == 1 && stride == 1 && KH == KW && (KH == 1 || KH == 3) && padH == KH / 2 && padW == KW / 2 && Cin <= 64 && !x2;
   ZT_REQUIRE(variant != 1 || ws_ok);
-  // producer / consumer kernel: 3x3, bf16 nhwc output, simple activation, 48 or 64 output channels per workgroup
-  const bool pc_ok = ws_ok && KH == 3 && out_mode == 0 && act <= 2 && (NT0 == 3 || NT0 == 4);
-  ZT_REQUIRE(variant != 3 || pc_ok);
-  static const int pc_auto = getenv("ZT_CONV_PC") ? atoi(getenv("ZT_CONV_PC")) : 1;
-  if (pc_ok && (variant == 3 || (variant == 0 && pc_auto && (long long)zt_cdiv(a.Wo, TW) * zt_cdiv(a.Ho, QTH) >= 2048))) {
-    a.tilesX = zt_cdiv(a.Wo, TW);
-    int rcp = launch_conv_pc(a, NT0, Cin <= 32 ? 1 : 2, stream);
+  // register-stationary kernel: 3x3, bf16 nhwc output, 48 or 64 couts, input channels <= 16, 33..48 (Cout 48) or 49..64 (Cout 64)
+  const bool rs_ok = ws_ok && KH == 3 && out_mode == 0 && act <= 2 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
+                     (!aux || (ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0)) && ldx >= 8 &&
+                     ((Cout == 64 && (Cin <= 16 || Cin == 56 || Cin == 64)) || (Cout == 48 && (Cin <= 16 || Cin == 40 || Cin == 48)));
+  ZT_REQUIRE(variant != 3 || rs_ok);
+  static const int rs_auto = getenv("ZT_CONV_RS") ? atoi(getenv("ZT_CONV_RS")) : 1;
+  if (rs_ok && (variant == 3 || (variant == 0 && rs_auto && (long long)zt_cdiv(a.Wo, TW) * zt_cdiv(a.Ho, RTH) >= 1024))) {
+    int rcp = launch_conv_rs(a, stream);
     if (rcp) return rcp;
     ZT_LAUNCH_CHECK();
     return ZT_OK;
