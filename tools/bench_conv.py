@@ -14,26 +14,26 @@ H, W = 1080, 1920
 
 
 def run(cin, cout, k, variant, epi=0, iters=10):
-    x = (torch.randn(1, H, W, cin, device=dev) * 0.5).bfloat16()
+    x = (torch.randn(1, H, W, (cin + 7) // 8 * 8, device=dev) * 0.5).bfloat16()
     w = torch.randn(cout, cin, k, k, device=dev) * 0.05
     wd = ops.repack_weight_bf16(w)
-    aux = x if epi else None
+    aux = torch.randn(1, H, W, (cout + 7) // 8 * 8, device=dev).bfloat16() if epi else None
     out = torch.empty(1, H, W, (cout + 7) // 8 * 8, device=dev, dtype=torch.bfloat16)
     for _ in range(2):
-        ops.conv2d_bf16(ops_mod.CV(x), wd, None, cout, k, k, (k // 2, k // 2), "relu", out=out, aux=aux, epi=epi, variant=variant)
+        ops.conv2d_bf16(ops_mod.CV(x, 0, cin), wd, None, cout, k, k, (k // 2, k // 2), "relu", out=out, aux=aux, epi=epi, variant=variant)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.conv2d_bf16(ops_mod.CV(x), wd, None, cout, k, k, (k // 2, k // 2), "relu", out=out, aux=aux, epi=epi, variant=variant)
+        ops.conv2d_bf16(ops_mod.CV(x, 0, cin), wd, None, cout, k, k, (k // 2, k // 2), "relu", out=out, aux=aux, epi=epi, variant=variant)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-names = {3: "register-stationary", 1: "ws full", 2: "tiled"}
+names = {3: "register-stationary", 33: "rs no-mfma", 34: "rs no-store", 36: "rs no-halo", 38: "rs mfma only", 39: "rs barriers only", 1: "ws full", 2: "tiled"}
 for (cin, cout, k) in ((64, 64, 3), (48, 48, 3)):
-    for v in (3, 1):
+    for v in (3, 33, 34, 36, 38, 39, 1):
         print("c%d->%d k%d  %-24s %8.1f us" % (cin, cout, k, names[v], run(cin, cout, k, v)), flush=True)
 print("c64->64 k3 ws full + residual epi %8.1f us" % run(64, 64, 3, 1, epi=3))
 print("c64->64 k3 rs + residual epi      %8.1f us" % run(64, 64, 3, 3, epi=3))

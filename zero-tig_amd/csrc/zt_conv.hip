@@ -989,10 +989,10 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
 
     if (EPI) {
       if (k >= 1) glds_aux(k - 1, k & 1);
-      if (k + 1 < n_my) load_halo(k + 1);
+      if (k + 1 < n_my && !(a.dbg & 4)) load_halo(k + 1);
     } else {
-      if (k + 1 < n_my) load_halo(k + 1);
-      if (k >= 1) store_tile(k - 1);
+      if (k + 1 < n_my && !(a.dbg & 4)) load_halo(k + 1);
+      if (k >= 1 && !(a.dbg & 2)) store_tile(k - 1);
     }
 
     // steps: halo row h (0..3) x kx x channel chunk; each step's fragments serve output rows r with ky = h - r in [0, 2]
@@ -1009,6 +1009,7 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
     }                                                                                                                 \
   }
     ZT_LOADX(0, 0)
+    if (!(a.dbg & 1))
     zt_static_for<0, NSTEP>([&](auto step_c) {
       constexpr int step = decltype(step_c)::value;
       constexpr int cur = step & 1;
@@ -1365,7 +1366,8 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   a.Wo = (W + 2 * padW - KW) / stride + 1;
   a.Cout = Cout; a.CoutP = CoutP; a.ldk = ldk; a.ldy = ldy; a.ldaux = ldaux;
   a.padH = padH; a.padW = padW; a.act = act; a.epi = epi; a.out_mode = out_mode; a.alpha = alpha;
-  a.dbg = variant >= 16 ? (variant - 16) : 0;
+  a.dbg = variant >= 32 ? (variant - 32) : (variant >= 16 ? (variant - 16) : 0);   // tuning ablations, see tools/bench_conv.py
+  if (variant >= 32) variant = 3;
   if (variant >= 16) variant = 1;
   ZT_REQUIRE(a.Ho > 0 && a.Wo > 0);
   a.tilesY = zt_cdiv(a.Ho, TH);
