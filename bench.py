@@ -173,13 +173,13 @@ def main():
             alg = (3 * (2 * px * 64 * 2) + 3 * (3 * px * 64 * 2)) / 6.0
             traffic = None
             try:        # measured HBM traffic of the same kernel from the committed PMC passes (profiles/, see its _how)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_summary.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_summary.json")))
                 if (H, W) == (1080, 1920):
-                    traffic = pm["kernels"]["conv_ws_bf16_kernel<3, 4, 2>"]["hbm_bytes_per_launch_avg"]
+                    traffic = pm["kernels"]["conv_rs_bf16_kernel<2, 2, true, 2, 0>"]["hbm_bytes_per_launch_avg"]
             except Exception:
                 pass
             gbs = alg / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "conv_ws_bf16_kernel<3,4,2> (Enhancer 64->64 3x3: 3 fwd + 3 dgrad launches per step)",
+            roof = {"bound": "hbm", "kernel": "conv_rs_bf16_kernel<2,2,true,2,0,*> (Enhancer 64->64 3x3: 3 fwd + 3 dgrad launches per step)",
                     "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic, "launches": len(ms),
                     "avg_ms": avg_ms, "algorithmic_bytes_per_launch": alg,
                     "mfma_view": {"achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_BF16_MFMA_TFLOPS, "frac": tf / PEAK_BF16_MFMA_TFLOPS,

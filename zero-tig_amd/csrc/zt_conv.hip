@@ -314,25 +314,32 @@ __global__ void __launch_bounds__(256) wgrad_mfma_f32_kernel(WgradArgs a) {
   }
 }
 
-// grad_w[co][ci][ky][kx] (+)= sum_slabs slab[s][tap][ci][co]; grad_b[co] (+)= sum_slabs slab[s][bias tail].  64 slab
-// elements (co fastest -> coalesced) x 4 slab groups per workgroup; fixed summation order (deterministic).
+// grad_w[co][ci][ky][kx] (+)= sum_slabs slab[s][tap][ci][co]; grad_b[co] (+)= sum_slabs slab[s][bias tail].  32 slab
+// elements (co fastest -> coalesced) x 8 slab groups per workgroup, eight loads in flight per thread; fixed summation order
+// (deterministic).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int ntap, int CT16,
                                                            int NT16, float* __restrict__ grad, int Cout, int Cin,
                                                            int accumulate, float* __restrict__ grad_b) {
   __shared__ float sh[256];
-  const int ex = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + ex;
+  const int ex = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + ex;
   const int nw = ntap * CT16 * NT16;
   const int total = nw + NT16;
   float s = 0.f;
   if (e < total) {
     const size_t stride = (size_t)total;
-    for (int k = sg; k < nslab; k += 4) s += slab[(size_t)k * stride + e];
+    for (int k = sg; k < nslab; k += 64) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (k + 8 * j < nslab) ? slab[(size_t)(k + 8 * j) * stride + e] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
   }
   sh[threadIdx.x] = s;
   __syncthreads();
   if (sg == 0 && e < total) {
-    s = ((sh[ex] + sh[64 + ex]) + sh[128 + ex]) + sh[192 + ex];
+    s = (((sh[ex] + sh[32 + ex]) + (sh[64 + ex] + sh[96 + ex])) + ((sh[128 + ex] + sh[160 + ex]) + (sh[192 + ex] + sh[224 + ex])));
     if (e < nw) {
       int co = e % NT16;
       int ci = (e / NT16) % CT16;
@@ -1126,47 +1133,68 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
   const int bco = tid % (NT * 16), bpart = tid / (NT * 16);
   float bsum = 0.f;
 
+  // global -> registers -> LDS staging, software-pipelined: the next tile's loads are issued before this tile's MFMAs and land
+  // while they run.  Loads are unconditional (clamped addresses); image borders and channel tails are masked when written.
+  constexpr int NXL = (IR * IC * CT * 2 + 255) / 256, NZL = (HTH * HTW * NT * 2 + 255) / 256;
+  uint4 px[NXL], pz[NZL];
+  auto chan_mask = [](uint4 v, int nv, bool in) {               // keep the first nv (of 8) bf16 lanes
+    const unsigned m0 = nv >= 2 ? ~0u : (nv == 1 ? 0xFFFFu : 0u), m1 = nv >= 4 ? ~0u : (nv == 3 ? 0xFFFFu : 0u);
+    const unsigned m2 = nv >= 6 ? ~0u : (nv == 5 ? 0xFFFFu : 0u), m3 = nv >= 8 ? ~0u : (nv == 7 ? 0xFFFFu : 0u);
+    v.x = in ? (v.x & m0) : 0u;
+    v.y = in ? (v.y & m1) : 0u;
+    v.z = in ? (v.z & m2) : 0u;
+    v.w = in ? (v.w & m3) : 0u;
+    return v;
+  };
+  auto load_tile = [&](int tile) {
+    const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      const int e = tid + i * 256;
+      const int c8 = e % (CT * 2), p = e / (CT * 2);
+      int gy = oy0 - padH + p / IC, gx = ox0 - padW + p % IC;
+      gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+      gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+      const int c = c8 * 8 + 8 <= a.ldx ? c8 * 8 : 0;
+      px[i] = *reinterpret_cast<const uint4*>(a.x + (unsigned)((gy * a.W + gx) * a.ldx + c));
+    }
+#pragma unroll
+    for (int i = 0; i < NZL; ++i) {
+      const int e = tid + i * 256;
+      const int c8 = e % (NT * 2), p = e / (NT * 2);
+      int gy = oy0 + p / HTW, gx = ox0 + p % HTW;
+      gy = gy >= a.H ? a.H - 1 : gy;
+      gx = gx >= a.W ? a.W - 1 : gx;
+      const int c = c8 * 8 + 8 <= a.lddz ? c8 * 8 : 0;
+      pz[i] = *reinterpret_cast<const uint4*>(a.dz + (unsigned)((gy * a.W + gx) * a.lddz + c));
+    }
+  };
+  auto write_tile = [&](int tile) {
+    const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      const int e = tid + i * 256;
+      const int c8 = e % (CT * 2), p = e / (CT * 2);
+      const int gy = oy0 - padH + p / IC, gx = ox0 - padW + p % IC;
+      const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      if (e < IR * IC * CT * 2) *reinterpret_cast<uint4*>(xs + p * CIP + c8 * 8) = chan_mask(px[i], a.Cin - c8 * 8, in);
+    }
+#pragma unroll
+    for (int i = 0; i < NZL; ++i) {
+      const int e = tid + i * 256;
+      const int c8 = e % (NT * 2), p = e / (NT * 2);
+      const int gy = oy0 + p / HTW, gx = ox0 + p % HTW;
+      const bool in = gy < a.H && gx < a.W;
+      if (e < HTH * HTW * NT * 2) *reinterpret_cast<uint4*>(zs + p * COP + c8 * 8) = chan_mask(pz[i], a.Cout - c8 * 8, in);
+    }
+  };
+
+  if ((int)blockIdx.x < a.ntiles) load_tile(blockIdx.x);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int tx = tile % a.tilesX, ty = tile / a.tilesX;
-    const int oy0 = ty * HTH, ox0 = tx * HTW;
     __syncthreads();
-    for (int e = tid; e < IR * IC * CT * 2; e += 256) {
-      int c8 = e % (CT * 2), p = e / (CT * 2);
-      int iy = p / IC, ixx = p - iy * IC;
-      int gy = oy0 - padH + iy, gx = ox0 - padW + ixx;
-      int c = c8 * 8;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.Cin) {
-        v = *reinterpret_cast<const uint4*>(a.x + ((size_t)gy * a.W + gx) * a.ldx + c);
-        if (c + 8 > a.Cin) {
-          zt_bf16 tmp[8];
-          __builtin_memcpy(tmp, &v, 16);
-          for (int j = 0; j < 8; ++j)
-            if (c + j >= a.Cin) tmp[j] = 0;
-          __builtin_memcpy(&v, tmp, 16);
-        }
-      }
-      *reinterpret_cast<uint4*>(xs + p * CIP + c) = v;
-    }
-    for (int e = tid; e < HTH * HTW * NT * 2; e += 256) {
-      int c8 = e % (NT * 2), p = e / (NT * 2);
-      int iy = p / HTW, ixx = p - iy * HTW;
-      int gy = oy0 + iy, gx = ox0 + ixx;
-      int c = c8 * 8;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (gy < a.H && gx < a.W && c < a.Cout) {
-        v = *reinterpret_cast<const uint4*>(a.dz + ((size_t)gy * a.W + gx) * a.lddz + c);
-        if (c + 8 > a.Cout) {
-          zt_bf16 tmp[8];
-          __builtin_memcpy(tmp, &v, 16);
-          for (int j = 0; j < 8; ++j)
-            if (c + j >= a.Cout) tmp[j] = 0;
-          __builtin_memcpy(&v, tmp, 16);
-        }
-      }
-      *reinterpret_cast<uint4*>(zs + p * COP + c) = v;
-    }
+    write_tile(tile);
     __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) load_tile(tile + gridDim.x);
     if (bpart < NPART)
       for (int p = bpart; p < HTH * HTW; p += NPART) bsum += zt_bf2f(zs[p * COP + bco]);
     // per-wave (tap, ci-tile) pairs: branch-free (a wave without a pair in the last round recomputes the final pair into an
@@ -1334,7 +1362,7 @@ extern "C" int zt_conv2d_wgrad_nhwc_f32(const float* x, int ldx, const float* dz
   else if (KH == 1 && KW == 1) rc = launch_wgrad<1, 1>(a, CT, NT, nblk, stream);
   if (rc) return rc;
   int total = KH * KW * CT * 16 * NT * 16 + NT * 16;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(zt_cdiv(total, 64)), dim3(256), 0, stream, (const float*)slab, nblk,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(zt_cdiv(total, 32)), dim3(256), 0, stream, (const float*)slab, nblk,
                      KH * KW, CT * 16, NT * 16, grad_w, Cout, Cin, accumulate, grad_b);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
@@ -1451,7 +1479,7 @@ extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
   else if (KH == 1 && KW == 1) rc = launch_wgrad_h<1, 1>(a, CT, NT, nblk, stream);
   if (rc) return rc;
   int total = KH * KW * CT * 16 * NT * 16 + NT * 16;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(zt_cdiv(total, 64)), dim3(256), 0, stream, (const float*)slab, nblk, KH * KW,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(zt_cdiv(total, 32)), dim3(256), 0, stream, (const float*)slab, nblk, KH * KW,
                      CT * 16, NT * 16, grad_w, Cout, Cin, accumulate, grad_b);
   ZT_LAUNCH_CHECK();
   return ZT_OK;

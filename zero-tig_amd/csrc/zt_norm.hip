@@ -62,10 +62,20 @@ __global__ void __launch_bounds__(256) norm_finalize_kernel(const float* __restr
     const int c = cbase + cl;
     double s = 0.0, q = 0.0;
     if (mode != 2 && grp < G && c < C) {
-      for (int b = grp; b < nblk; b += G) {
-        const float* p = partial + ((size_t)(n * nblk + b) * 2) * C;
-        s += (double)p[c];
-        q += (double)p[C + c];
+      for (int b = grp; b < nblk; b += 8 * G) {              // eight partial rows in flight; same summation order as a plain loop
+        float ps[8], pq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int bb = b + j * G;
+          const float* p = partial + ((size_t)(n * nblk + (bb < nblk ? bb : b)) * 2) * C;
+          ps[j] = bb < nblk ? p[c] : 0.f;
+          pq[j] = bb < nblk ? p[C + c] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          s += (double)ps[j];
+          q += (double)pq[j];
+        }
       }
     }
     sh_s[threadIdx.x] = s;
