@@ -1110,12 +1110,14 @@ struct WgradArgsH {
 
 constexpr int HTH = 4, HTW = 32;
 
-template <int KH, int KW, int CT, int NT>
-__global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
+// NW waves per workgroup share the (tap, ci-tile) pairs; 8 for the 64x64 layer so that accumulators + staging registers stay <= 128
+template <int KH, int KW, int CT, int NT, int NW>
+__global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) {
+  constexpr int NTHR = NW * 64;
   constexpr int IR = HTH + KH - 1, IC = HTW + KW - 1;
   constexpr int CIP = CT * 16 + 8, COP = NT * 16 + 8;
   constexpr int NPAIR = KH * KW * CT;
-  constexpr int PPW = (NPAIR + 3) / 4;
+  constexpr int PPW = (NPAIR + NW - 1) / NW;
   constexpr int padH = (KH - 1) / 2, padW = (KW - 1) / 2;
   __shared__ __attribute__((aligned(16))) zt_bf16 xs[IR * IC * CIP];
   __shared__ __attribute__((aligned(16))) zt_bf16 zs[HTH * HTW * COP];
@@ -1129,13 +1131,13 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
   for (int p = 0; p < PPW; ++p)
 #pragma unroll
     for (int q = 0; q < NT; ++q) acc[p][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int NPART = 256 / (NT * 16);
+  constexpr int NPART = NTHR / (NT * 16);
   const int bco = tid % (NT * 16), bpart = tid / (NT * 16);
   float bsum = 0.f;
 
   // global -> registers -> LDS staging, software-pipelined: the next tile's loads are issued before this tile's MFMAs and land
   // while they run.  Loads are unconditional (clamped addresses); image borders and channel tails are masked when written.
-  constexpr int NXL = (IR * IC * CT * 2 + 255) / 256, NZL = (HTH * HTW * NT * 2 + 255) / 256;
+  constexpr int NXL = (IR * IC * CT * 2 + NTHR - 1) / NTHR, NZL = (HTH * HTW * NT * 2 + NTHR - 1) / NTHR;
   uint4 px[NXL], pz[NZL];
   auto chan_mask = [](uint4 v, int nv, bool in) {               // keep the first nv (of 8) bf16 lanes
     const unsigned m0 = nv >= 2 ? ~0u : (nv == 1 ? 0xFFFFu : 0u), m1 = nv >= 4 ? ~0u : (nv == 3 ? 0xFFFFu : 0u);
@@ -1150,7 +1152,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
     const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NTHR;
       const int c8 = e % (CT * 2), p = e / (CT * 2);
       int gy = oy0 - padH + p / IC, gx = ox0 - padW + p % IC;
       gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
@@ -1160,7 +1162,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
     }
 #pragma unroll
     for (int i = 0; i < NZL; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NTHR;
       const int c8 = e % (NT * 2), p = e / (NT * 2);
       int gy = oy0 + p / HTW, gx = ox0 + p % HTW;
       gy = gy >= a.H ? a.H - 1 : gy;
@@ -1173,7 +1175,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
     const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NTHR;
       const int c8 = e % (CT * 2), p = e / (CT * 2);
       const int gy = oy0 - padH + p / IC, gx = ox0 - padW + p % IC;
       const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
@@ -1181,7 +1183,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
     }
 #pragma unroll
     for (int i = 0; i < NZL; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NTHR;
       const int c8 = e % (NT * 2), p = e / (NT * 2);
       const int gy = oy0 + p / HTW, gx = ox0 + p % HTW;
       const bool in = gy < a.H && gx < a.W;
@@ -1202,7 +1204,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
     int aoff[PPW];
 #pragma unroll
     for (int pi = 0; pi < PPW; ++pi) {
-      int pr = wave + 4 * pi;
+      int pr = wave + NW * pi;
       pr = pr < NPAIR ? pr : NPAIR - 1;
       const int tap = pr / CT, cit = pr - tap * CT;
       const int ky = tap / KW, kx = tap - ky * KW;
@@ -1240,7 +1242,7 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
   const int l4 = lane >> 4;
 #pragma unroll
   for (int pi = 0; pi < PPW; ++pi) {
-    const int pr = wave + 4 * pi;
+    const int pr = wave + NW * pi;
     if (pr < NPAIR) {
       const int tap = pr / CT, cit = pr - tap * CT;
 #pragma unroll
@@ -1263,14 +1265,14 @@ __global__ void __launch_bounds__(256) wgrad_mfma_bf16_kernel(WgradArgsH a) {
 
 template <int KH, int KW>
 int launch_wgrad_h(const WgradArgsH& a, int CT, int NT, int nblk, hipStream_t stream) {
-  dim3 grid(nblk), block(256);
-#define ZT_WG(ct, nt) hipLaunchKernelGGL((wgrad_mfma_bf16_kernel<KH, KW, ct, nt>), grid, block, 0, stream, a); return 0
-  if (CT == 1 && NT == 3) { ZT_WG(1, 3); }
-  if (CT == 1 && NT == 4) { ZT_WG(1, 4); }
-  if (CT == 3 && NT == 3) { ZT_WG(3, 3); }
-  if (CT == 3 && NT == 1) { ZT_WG(3, 1); }
-  if (CT == 4 && NT == 4) { ZT_WG(4, 4); }
-  if (CT == 4 && NT == 1) { ZT_WG(4, 1); }
+  dim3 grid(nblk);
+#define ZT_WG(ct, nt, nw) hipLaunchKernelGGL((wgrad_mfma_bf16_kernel<KH, KW, ct, nt, nw>), grid, dim3(nw * 64), 0, stream, a); return 0
+  if (CT == 1 && NT == 3) { ZT_WG(1, 3, 4); }
+  if (CT == 1 && NT == 4) { ZT_WG(1, 4, 4); }
+  if (CT == 3 && NT == 3) { ZT_WG(3, 3, 4); }
+  if (CT == 3 && NT == 1) { ZT_WG(3, 1, 4); }
+  if (CT == 4 && NT == 4) { ZT_WG(4, 4, 8); }
+  if (CT == 4 && NT == 1) { ZT_WG(4, 1, 4); }
 #undef ZT_WG
   return ZT_EINVAL;
 }

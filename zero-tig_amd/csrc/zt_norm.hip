@@ -45,36 +45,38 @@ __global__ void __launch_bounds__(256) chan_stats_kernel(const T* __restrict__ x
 
 // mode 0: instance norm (per n,c; no affine)   mode 1: train BN (N must be 1; updates running stats)   mode 2: eval BN
 // 256 threads = G groups x C channels (G = 256 / C): each group sums a strided share of the partials, fp64 combine in LDS.
-__global__ void __launch_bounds__(256) norm_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+__global__ void __launch_bounds__(1024) norm_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                             double count, float eps, int mode,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
                                                             long long* __restrict__ nbt, float momentum,
                                                             float* __restrict__ scale, float* __restrict__ shift,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-  __shared__ double sh_s[256];
-  __shared__ double sh_q[256];
+  __shared__ double sh_s[1024];
+  __shared__ double sh_q[1024];
   const int n = blockIdx.x;
   const int Cb = C < 256 ? C : 256;                 // channels handled per pass
-  const int G = 256 / Cb;
+  const int G = 1024 / Cb;                          // partial-row groups: 1024 threads keep the serial chain short
   for (int cbase = 0; cbase < C; cbase += Cb) {
     const int cl = threadIdx.x % Cb, grp = threadIdx.x / Cb;
     const int c = cbase + cl;
     double s = 0.0, q = 0.0;
     if (mode != 2 && grp < G && c < C) {
+      const float* pc = partial + (size_t)n * nblk * 2 * C + c;
       for (int b = grp; b < nblk; b += 8 * G) {              // eight partial rows in flight; same summation order as a plain loop
         float ps[8], pq[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 8; ++j) {                          // unconditional loads (clamped row), masked afterwards
           const int bb = b + j * G;
-          const float* p = partial + ((size_t)(n * nblk + (bb < nblk ? bb : b)) * 2) * C;
-          ps[j] = bb < nblk ? p[c] : 0.f;
-          pq[j] = bb < nblk ? p[C + c] : 0.f;
+          const unsigned off = (unsigned)(bb < nblk ? bb : b) * 2u * (unsigned)C;
+          ps[j] = pc[off];
+          pq[j] = pc[off + C];
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          s += (double)ps[j];
-          q += (double)pq[j];
+          const bool ok = b + j * G < nblk;
+          s += ok ? (double)ps[j] : 0.0;
+          q += ok ? (double)pq[j] : 0.0;
         }
       }
     }
@@ -255,7 +257,7 @@ extern "C" int zt_norm_finalize_f32(const float* partial, int nblk, int N, int C
   ZT_REQUIRE(scale && shift && (mode == 2 || partial) && (mode == 0 || (gamma && beta)));
   ZT_REQUIRE(mode == 0 || (running_mean && running_var));
   ZT_REQUIRE(mode != 1 || N == 1);
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3(N), dim3(256), 0, stream, partial, nblk, C, (double)count, eps, mode, gamma,
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(N), dim3(1024), 0, stream, partial, nblk, C, (double)count, eps, mode, gamma,
                      beta, running_mean, running_var, num_batches_tracked, momentum, scale, shift, mean_out, rstd_out);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
