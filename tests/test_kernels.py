@@ -237,6 +237,37 @@ def test_norms(backend):
     assert maxerr(dg, gam_t.grad) < 2e-4 and maxerr(db, bet_t.grad) < 2e-4
 
 
+def test_norms_bf16_fast_path(backend):
+    """Enhancer block in bf16 storage at a size that takes the 16-byte-per-lane kernels (HW >= 4096, C % 8 == 0): train BN +
+    ReLU + residual forward and backward against torch on the same bf16-rounded inputs; ragged pixel count (not a multiple of 4)."""
+    import torch.nn.functional as F
+    ops, dev, _ = backend
+    g = torch.Generator().manual_seed(23)
+    C, H, W = 64, 67, 63
+    bf = lambda t: t.bfloat16().float()
+    f = bf(torch.randn(1, C, H, W, generator=g))
+    z0 = bf(torch.randn(1, C, H, W, generator=g) * 1.7 + 0.3)
+    z = z0.clone().requires_grad_(True)
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    gam_t, bet_t = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    out_ref = f + F.relu(F.batch_norm(z, rm.clone(), rv.clone(), gam_t, bet_t, True, 0.1, 1e-5))
+    dy = bf(torch.randn(1, C, H, W, generator=g))
+    (out_ref * dy).sum().backward()
+    zd, fd, dyd = (_nhwc(t).bfloat16().to(dev) for t in (z0, f, dy))
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    part = ops.chan_stats(zd)
+    sc, sh, mu, rs = ops.norm_finalize(part, 1, C, H * W, 1, gam.to(dev), bet.to(dev), rm.to(dev), rv.to(dev), nbt)
+    y = ops.norm_apply(zd, sc, sh, res=fd, inner_relu=True)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert float(((got - out_ref.detach()).abs() - out_ref.detach().abs() * 2 ** -8).max()) < 1e-3
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dz = ops.bn_relu_bwd(dyd, zd, sc, sh, mu, rs, dg, db)
+    gz = dz.float().cpu().permute(0, 3, 1, 2)
+    assert float(((gz - z.grad).abs() - z.grad.abs() * 2 ** -8).max()) < 1e-3
+    assert maxerr(dg, gam_t.grad) < 2e-3 * float(gam_t.grad.abs().max()) and maxerr(db, bet_t.grad) < 2e-3 * float(bet_t.grad.abs().max())
+
+
 def test_raft_ops_golden(backend, oracle, synth):
     """corr volume (as MFMA 1x1 conv) + pyramid + fused lookup, equalize, one update-block step + convex upsample (G6)."""
     from importlib import import_module

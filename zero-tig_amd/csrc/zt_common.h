@@ -127,6 +127,25 @@ template <> struct ZtIO<zt_bf16> {
   static __device__ __forceinline__ void st(zt_bf16* p, float v) { *p = zt_f2bf(v); }
 };
 
+// eight consecutive bf16 channels <-> eight floats (one 16-byte access per lane: the width the HBM path wants)
+__device__ __forceinline__ void zt_ld8(const zt_bf16* p, float (&f)[8]) {
+  const uint4 r = *reinterpret_cast<const uint4*>(p);
+  const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = zt_u2f(w[j] << 16);
+    f[2 * j + 1] = zt_u2f(w[j] & 0xFFFF0000u);
+  }
+}
+__device__ __forceinline__ void zt_st8(zt_bf16* p, const float (&f)[8]) {
+  uint4 r;
+  r.x = zt_f2bf2(f[0], f[1]);
+  r.y = zt_f2bf2(f[2], f[3]);
+  r.z = zt_f2bf2(f[4], f[5]);
+  r.w = zt_f2bf2(f[6], f[7]);
+  *reinterpret_cast<uint4*>(p) = r;
+}
+
 // D = A(16x32 bf16) * B(32x16 bf16) + C: lane l holds A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15], j = 0..7
 __device__ __forceinline__ zt_f32x4 zt_mfma_bf16(zt_s16x8 a, zt_s16x8 b, zt_f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(zt_bf16x8, a), __builtin_bit_cast(zt_bf16x8, b), c, 0, 0, 0);

@@ -241,10 +241,175 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
 
 }  // namespace
 
+
+// ---- bf16 fast paths for the full-resolution tensors (C % 8 == 0, 16-byte aligned rows): one 16-byte access per lane, PIX
+// pixels per thread so the per-channel parameters are loaded once and several loads are in flight.  Thread i: channel octet
+// i % Q8, pixels (i / Q8) + j * npg, j < PIX -- load j of a wave covers 64 / Q8 consecutive pixels (contiguous KBs).
+constexpr int NPIX = 4;
+
+__global__ void __launch_bounds__(256) norm_apply_bf16x8_kernel(const zt_bf16* __restrict__ x, int ldx,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const zt_bf16* __restrict__ res, int ldres,
+                                                                zt_bf16* __restrict__ y, int ldy, int HW, int C, int npg,
+                                                                int inner_relu, int outer_relu) {
+  const int Q8 = C >> 3;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int o = (int)(i % Q8), pg = (int)(i / Q8);
+  if (pg >= npg) return;
+  float sc[8], sf[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    sc[c] = scale[o * 8 + c];
+    sf[c] = shift[o * 8 + c];
+  }
+  float v[NPIX][8], r[NPIX][8];
+#pragma unroll
+  for (int j = 0; j < NPIX; ++j) {
+    const int p = min(pg + j * npg, HW - 1);
+    zt_ld8(x + (size_t)p * ldx + o * 8, v[j]);
+    if (res) zt_ld8(res + (size_t)p * ldres + o * 8, r[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NPIX; ++j) {
+    const int p = pg + j * npg;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float t = v[j][c] * sc[c] + sf[c];
+      if (inner_relu) t = fmaxf(t, 0.f);
+      if (res) t += r[j][c];
+      if (outer_relu) t = fmaxf(t, 0.f);
+      v[j][c] = t;
+    }
+    if (p < HW) zt_st8(y + (size_t)p * ldy + o * 8, v[j]);
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_bf16x8_kernel(const zt_bf16* __restrict__ dy, int lddy,
+                                                                  const zt_bf16* __restrict__ z, int ldz,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ sums, float inv_n,
+                                                                  zt_bf16* __restrict__ dz, int lddz, int HW, int C, int npg,
+                                                                  int eval_mode) {
+  const int Q8 = C >> 3;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int o = (int)(i % Q8), pg = (int)(i / Q8);
+  if (pg >= npg) return;
+  float sc[8], sf[8], mu[8], rs[8], a1[8], a2[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    sc[c] = scale[o * 8 + c];
+    sf[c] = shift[o * 8 + c];
+    mu[c] = mean[o * 8 + c];
+    rs[c] = rstd[o * 8 + c];
+    a1[c] = sums[o * 8 + c] * inv_n;
+    a2[c] = sums[C + o * 8 + c] * inv_n;
+  }
+  float g[NPIX][8], v[NPIX][8];
+#pragma unroll
+  for (int j = 0; j < NPIX; ++j) {
+    const int p = min(pg + j * npg, HW - 1);
+    zt_ld8(dy + (size_t)p * lddy + o * 8, g[j]);
+    zt_ld8(z + (size_t)p * ldz + o * 8, v[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NPIX; ++j) {
+    const int p = pg + j * npg;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float gg = (v[j][c] * sc[c] + sf[c] > 0.f) ? g[j][c] : 0.f;
+      const float zh = (v[j][c] - mu[c]) * rs[c];
+      g[j][c] = eval_mode ? sc[c] * gg : sc[c] * (gg - a1[c] - zh * a2[c]);
+    }
+    if (p < HW) zt_st8(dz + (size_t)p * lddz + o * 8, g[j]);
+  }
+}
+
+// statistics: block = 256 threads = (256 / Q8) pixel rows x Q8 octets; NPIX rows in flight per thread.  MODE 0: sum x, sum x^2
+// (chan_stats); MODE 1: sum g, sum g * xhat with g = dy masked by the ReLU of the BN output (bn_bwd_reduce).
+template <int MODE>
+__global__ void __launch_bounds__(256) stats_bf16x8_kernel(const zt_bf16* __restrict__ x, int ldx, const zt_bf16* __restrict__ dy,
+                                                           int lddy, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, int HW, int C, int nblk,
+                                                           float* __restrict__ partial) {
+  __shared__ float sh[2][8][256];
+  const int Q8 = C >> 3, R = 256 / Q8;
+  const int tid = threadIdx.x;
+  const int row = tid / Q8, o = tid - row * Q8;
+  const int n = blockIdx.y, blk = blockIdx.x;
+  const int chunk = (HW + nblk - 1) / nblk;
+  const int p0 = blk * chunk, p1 = min(HW, p0 + chunk);
+  float sa[8], sb[8], sc[8], sf[8], mu[8], rs[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    sa[c] = 0.f;
+    sb[c] = 0.f;
+    if (MODE == 1) {
+      sc[c] = scale[o * 8 + c];
+      sf[c] = shift[o * 8 + c];
+      mu[c] = mean[o * 8 + c];
+      rs[c] = rstd[o * 8 + c];
+    }
+  }
+  if (row < R) {
+    const zt_bf16* xb = x + (size_t)n * HW * ldx + o * 8;
+    for (int p = p0 + row; p < p1; p += NPIX * R) {
+      float v[NPIX][8], g[NPIX][8];
+#pragma unroll
+      for (int j = 0; j < NPIX; ++j) {
+        const int pp = min(p + j * R, p1 - 1);
+        zt_ld8(xb + (size_t)pp * ldx, v[j]);
+        if (MODE == 1) zt_ld8(dy + (size_t)pp * lddy + o * 8, g[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < NPIX; ++j) {
+        const bool ok = p + j * R < p1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (MODE == 0) {
+            const float t = ok ? v[j][c] : 0.f;
+            sa[c] += t;
+            sb[c] += t * t;
+          } else {
+            const float gg = (ok && v[j][c] * sc[c] + sf[c] > 0.f) ? g[j][c] : 0.f;
+            sa[c] += gg;
+            sb[c] += gg * ((v[j][c] - mu[c]) * rs[c]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    sh[0][c][tid] = sa[c];
+    sh[1][c][tid] = sb[c];
+  }
+  __syncthreads();
+  if (row == 0) {
+    float* ob = partial + ((size_t)(n * nblk + blk) * 2) * C + o * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float a = sa[c], b = sb[c];
+      for (int r = 1; r < R; ++r) {
+        a += sh[0][c][r * Q8 + o];
+        b += sh[1][c][r * Q8 + o];
+      }
+      ob[c] = a;
+      ob[C + c] = b;
+    }
+  }
+}
+
+static inline bool zt_x8_ok(const void* p, int ld, int C) { return C % 8 == 0 && ld % 8 == 0 && ((uintptr_t)p & 15) == 0 && 256 % (C / 8) == 0; }
+
 extern "C" int zt_chan_stats_nhwc(const void* x, int dt, int ldx, int N, int HW, int C, int nblk, float* partial,
                                   hipStream_t stream) {
   ZT_REQUIRE(x && partial && C % 4 == 0 && C >= 4 && C <= 1024 && ldx % 4 == 0 && nblk > 0 && ((uintptr_t)x & 7) == 0);
   if (dt == 0) hipLaunchKernelGGL(chan_stats_kernel<float>, dim3(nblk, N), dim3(256), 0, stream, (const float*)x, ldx, HW, C, nblk, partial);
+  else if (zt_x8_ok(x, ldx, C) && HW >= 4096)
+    hipLaunchKernelGGL(stats_bf16x8_kernel<0>, dim3(nblk, N), dim3(256), 0, stream, (const zt_bf16*)x, ldx, (const zt_bf16*)nullptr, 0,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, HW, C, nblk, partial);
   else hipLaunchKernelGGL(chan_stats_kernel<zt_bf16>, dim3(nblk, N), dim3(256), 0, stream, (const zt_bf16*)x, ldx, HW, C, nblk, partial);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
@@ -268,7 +433,11 @@ extern "C" int zt_norm_apply_nhwc(const void* x, int dt, int ldx, const float* s
                                   hipStream_t stream) {
   ZT_REQUIRE(x && y && scale && shift && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!res || ldres % 4 == 0));
   long long total4 = (long long)N * HW * (C / 4);
-  if (dt == 0)
+  if (dt != 0 && N == 1 && HW >= 4096 && zt_x8_ok(x, ldx, C) && zt_x8_ok(y, ldy, C) && (!res || zt_x8_ok(res, ldres, C))) {
+    const int npg = zt_cdiv(HW, NPIX);
+    hipLaunchKernelGGL(norm_apply_bf16x8_kernel, dim3((unsigned)zt_cdivl((long long)npg * (C / 8), 256)), dim3(256), 0, stream,
+                       (const zt_bf16*)x, ldx, scale, shift, (const zt_bf16*)res, ldres, (zt_bf16*)y, ldy, HW, C, npg, inner_relu, outer_relu);
+  } else if (dt == 0)
     hipLaunchKernelGGL(norm_apply_kernel<float>, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, (const float*)x, ldx,
                        scale, shift, (const float*)res, ldres, (float*)y, ldy, HW, C, inner_relu, outer_relu, total4);
   else
@@ -282,7 +451,10 @@ extern "C" int zt_bn_bwd_reduce(const void* dy, int dt, int lddy, const void* z,
                                 const float* shift, const float* mean, const float* rstd, int HW, int C, int nblk,
                                 float* partial, hipStream_t stream) {
   ZT_REQUIRE(dy && z && partial && C % 4 == 0 && C <= 1024);
-  if (dt == 0)
+  if (dt != 0 && HW >= 4096 && zt_x8_ok(dy, lddy, C) && zt_x8_ok(z, ldz, C))
+    hipLaunchKernelGGL(stats_bf16x8_kernel<1>, dim3(nblk, 1), dim3(256), 0, stream, (const zt_bf16*)z, ldz, (const zt_bf16*)dy, lddy, scale,
+                       shift, mean, rstd, HW, C, nblk, partial);
+  else if (dt == 0)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, stream, (const float*)dy, lddy, (const float*)z, ldz,
                        scale, shift, mean, rstd, HW, C, nblk, partial);
   else
@@ -305,7 +477,12 @@ extern "C" int zt_bn_bwd_apply(const void* dy, int dt, int lddy, const void* z, 
                                void* dz, int lddz, int HW, int C, int eval_mode, hipStream_t stream) {
   ZT_REQUIRE(dy && z && dz && sums && C % 4 == 0);
   long long total4 = (long long)HW * (C / 4);
-  if (dt == 0)
+  if (dt != 0 && HW >= 4096 && zt_x8_ok(dy, lddy, C) && zt_x8_ok(z, ldz, C) && zt_x8_ok(dz, lddz, C)) {
+    const int npg = zt_cdiv(HW, NPIX);
+    hipLaunchKernelGGL(bn_bwd_apply_bf16x8_kernel, dim3((unsigned)zt_cdivl((long long)npg * (C / 8), 256)), dim3(256), 0, stream,
+                       (const zt_bf16*)dy, lddy, (const zt_bf16*)z, ldz, scale, shift, mean, rstd, sums, 1.f / (float)HW, (zt_bf16*)dz, lddz,
+                       HW, C, npg, eval_mode);
+  } else if (dt == 0)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, (const float*)dy,
                        lddy, (const float*)z, ldz, scale, shift, mean, rstd, sums, 1.f / (float)HW, (float*)dz, lddz, C, eval_mode, total4);
   else

@@ -217,7 +217,7 @@ class Ops:
 
     # ---- normalisation (zt_norm.hip) --------------------------------------------------------------------------
     def _nblk(self, HW):
-        return max(1, min(512, HW // 64))
+        return max(1, min(1024, HW // 64))
 
     def chan_stats(self, x, nblk=None):
         """-> partial [N, nblk, 2, C] (sum, sum of squares) for a CV/tensor NHWC."""
