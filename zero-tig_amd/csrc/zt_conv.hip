@@ -421,7 +421,32 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
 #pragma unroll
     for (int q = 0; q < NT; ++q) acc[m][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
 
+  constexpr int NWS = (TG * NT * 16 * 4 + 255) / 256;
+  uint4 wv[NWS];
   for (int c0 = 0; c0 < a.Cin; c0 += HCK) {
+    auto load_w = [&](int grp) {
+#pragma unroll
+      for (int i = 0; i < NWS; ++i) {
+        const int e = tid + i * 256;
+        const int q = e & 3, r = e >> 2;
+        const int co = r % (NT * 16), tl = r / (NT * 16);
+        int tap = grp * TG + tl;
+        tap = tap < KH * KW ? tap : KH * KW - 1;
+        const int c = c0 + q * 8;
+        const int cor = co0 + co < a.CoutP ? co0 + co : a.CoutP - 1;
+        wv[i] = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.CoutP + cor) * a.ldk + (c < a.ldk ? c : 0));
+      }
+    };
+    auto write_w = [&]() {
+#pragma unroll
+      for (int i = 0; i < NWS; ++i) {
+        const int e = tid + i * 256;
+        const int q = e & 3, r = e >> 2;
+        const int co = r % (NT * 16), tl = r / (NT * 16);
+        const bool ok = c0 + q * 8 < a.ldk && co0 + co < a.CoutP;
+        if (e < TG * NT * 16 * 4) *reinterpret_cast<uint4*>(ws + (tl * NT * 16 + co) * HCKP + q * 8) = ok ? wv[i] : make_uint4(0u, 0u, 0u, 0u);
+      }
+    };
     __syncthreads();
     {
       const bool second = a.x2 != nullptr && c0 >= a.csplit;
@@ -429,40 +454,42 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
       const int ld = second ? a.ldx2 : a.ldx;
       const int cbase = second ? c0 - a.csplit : c0;
       const int climit = second ? a.Cin - a.csplit : (a.x2 ? a.csplit : a.Cin);
-      for (int e = tid; e < IR * IC * 4; e += 256) {
-        int p = e >> 2, q = e & 3;
-        int iy = p / IC, ixx = p - iy * IC;
-        int gy = gy0 + iy, gx = gx0 + ixx;
-        int c = cbase + q * 8;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < climit) {
-          const zt_bf16* g = src + ((size_t)(n * a.H + gy) * a.W + gx) * ld + c;
-          v = *reinterpret_cast<const uint4*>(g);
-          if (c + 8 > climit) {            // ragged tail: keep only the valid channels
-            zt_bf16 tmp[8];
-            __builtin_memcpy(tmp, &v, 16);
-            for (int j = 0; j < 8; ++j)
-              if (c + j >= climit) tmp[j] = 0;
-            __builtin_memcpy(&v, tmp, 16);
-          }
-        }
-        *reinterpret_cast<uint4*>(xs + p * HCKP + q * 8) = v;
+      // all loads of the chunk first (clamped addresses, no branches), then mask + write: one exposed latency per chunk
+      constexpr int NXS = (IR * IC * 4 + 255) / 256;
+      uint4 xv[NXS];
+#pragma unroll
+      for (int i = 0; i < NXS; ++i) {
+        const int e = tid + i * 256;
+        const int p = e >> 2, q = e & 3;
+        int gy = gy0 + p / IC, gx = gx0 + p % IC;
+        gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+        gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+        const int c = cbase + q * 8;
+        xv[i] = *reinterpret_cast<const uint4*>(src + (size_t)((n * a.H + gy) * a.W + gx) * ld + (c < ld ? c : 0));
+      }
+      load_w(0);                                                // the first tap group's weights fly together with the pixels
+#pragma unroll
+      for (int i = 0; i < NXS; ++i) {
+        const int e = tid + i * 256;
+        const int p = e >> 2, q = e & 3;
+        const int gy = gy0 + p / IC, gx = gx0 + p % IC;
+        const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const int nv = climit - (cbase + q * 8);                // valid channels of this 8-chunk (ragged tail / beyond the input)
+        const unsigned m0 = nv >= 2 ? ~0u : (nv == 1 ? 0xFFFFu : 0u), m1 = nv >= 4 ? ~0u : (nv == 3 ? 0xFFFFu : 0u);
+        const unsigned m2 = nv >= 6 ? ~0u : (nv == 5 ? 0xFFFFu : 0u), m3 = nv >= 8 ? ~0u : (nv == 7 ? 0xFFFFu : 0u);
+        uint4 v = xv[i];
+        v.x = in ? (v.x & m0) : 0u;
+        v.y = in ? (v.y & m1) : 0u;
+        v.z = in ? (v.z & m2) : 0u;
+        v.w = in ? (v.w & m3) : 0u;
+        if (e < IR * IC * 4) *reinterpret_cast<uint4*>(xs + p * HCKP + q * 8) = v;
       }
     }
 #pragma unroll 1
     for (int grp = 0; grp < NG; ++grp) {
       if (grp > 0) __syncthreads();
-      for (int e = tid; e < TG * NT * 16 * 4; e += 256) {
-        int q = e & 3;
-        int r = e >> 2;
-        int co = r % (NT * 16), tl = r / (NT * 16);
-        int tap = grp * TG + tl;
-        int c = c0 + q * 8;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (c < a.ldk && co0 + co < a.CoutP)
-          v = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.CoutP + co0 + co) * a.ldk + c);
-        *reinterpret_cast<uint4*>(ws + (tl * NT * 16 + co) * HCKP + q * 8) = v;
-      }
+      if (grp > 0) load_w(grp);
+      write_w();
       __syncthreads();
 #pragma unroll
       for (int tl = 0; tl < TG; ++tl) {
