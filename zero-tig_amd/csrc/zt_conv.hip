@@ -421,76 +421,91 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
 #pragma unroll
     for (int q = 0; q < NT; ++q) acc[m][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // global -> registers -> LDS, software-pipelined over the 32-channel chunks: all loads of a chunk are issued together
+  // (clamped addresses, no branches; borders and ragged channel tails are masked when written) and the NEXT chunk's loads are
+  // issued before this chunk's MFMAs, so one global latency is exposed per launch rather than several per chunk.
   constexpr int NWS = (TG * NT * 16 * 4 + 255) / 256;
-  uint4 wv[NWS];
-  for (int c0 = 0; c0 < a.Cin; c0 += HCK) {
-    auto load_w = [&](int grp) {
+  constexpr int NXS = (IR * IC * 4 + 255) / 256;
+  uint4 wv[NWS], xv[NXS];
+  auto load_w = [&](int c0, int grp) {
 #pragma unroll
-      for (int i = 0; i < NWS; ++i) {
-        const int e = tid + i * 256;
-        const int q = e & 3, r = e >> 2;
-        const int co = r % (NT * 16), tl = r / (NT * 16);
-        int tap = grp * TG + tl;
-        tap = tap < KH * KW ? tap : KH * KW - 1;
-        const int c = c0 + q * 8;
-        const int cor = co0 + co < a.CoutP ? co0 + co : a.CoutP - 1;
-        wv[i] = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.CoutP + cor) * a.ldk + (c < a.ldk ? c : 0));
-      }
-    };
-    auto write_w = [&]() {
-#pragma unroll
-      for (int i = 0; i < NWS; ++i) {
-        const int e = tid + i * 256;
-        const int q = e & 3, r = e >> 2;
-        const int co = r % (NT * 16), tl = r / (NT * 16);
-        const bool ok = c0 + q * 8 < a.ldk && co0 + co < a.CoutP;
-        if (e < TG * NT * 16 * 4) *reinterpret_cast<uint4*>(ws + (tl * NT * 16 + co) * HCKP + q * 8) = ok ? wv[i] : make_uint4(0u, 0u, 0u, 0u);
-      }
-    };
-    __syncthreads();
-    {
-      const bool second = a.x2 != nullptr && c0 >= a.csplit;
-      const zt_bf16* src = second ? a.x2 : a.x;
-      const int ld = second ? a.ldx2 : a.ldx;
-      const int cbase = second ? c0 - a.csplit : c0;
-      const int climit = second ? a.Cin - a.csplit : (a.x2 ? a.csplit : a.Cin);
-      // all loads of the chunk first (clamped addresses, no branches), then mask + write: one exposed latency per chunk
-      constexpr int NXS = (IR * IC * 4 + 255) / 256;
-      uint4 xv[NXS];
-#pragma unroll
-      for (int i = 0; i < NXS; ++i) {
-        const int e = tid + i * 256;
-        const int p = e >> 2, q = e & 3;
-        int gy = gy0 + p / IC, gx = gx0 + p % IC;
-        gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
-        gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-        const int c = cbase + q * 8;
-        xv[i] = *reinterpret_cast<const uint4*>(src + (size_t)((n * a.H + gy) * a.W + gx) * ld + (c < ld ? c : 0));
-      }
-      load_w(0);                                                // the first tap group's weights fly together with the pixels
-#pragma unroll
-      for (int i = 0; i < NXS; ++i) {
-        const int e = tid + i * 256;
-        const int p = e >> 2, q = e & 3;
-        const int gy = gy0 + p / IC, gx = gx0 + p % IC;
-        const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const int nv = climit - (cbase + q * 8);                // valid channels of this 8-chunk (ragged tail / beyond the input)
-        const unsigned m0 = nv >= 2 ? ~0u : (nv == 1 ? 0xFFFFu : 0u), m1 = nv >= 4 ? ~0u : (nv == 3 ? 0xFFFFu : 0u);
-        const unsigned m2 = nv >= 6 ? ~0u : (nv == 5 ? 0xFFFFu : 0u), m3 = nv >= 8 ? ~0u : (nv == 7 ? 0xFFFFu : 0u);
-        uint4 v = xv[i];
-        v.x = in ? (v.x & m0) : 0u;
-        v.y = in ? (v.y & m1) : 0u;
-        v.z = in ? (v.z & m2) : 0u;
-        v.w = in ? (v.w & m3) : 0u;
-        if (e < IR * IC * 4) *reinterpret_cast<uint4*>(xs + p * HCKP + q * 8) = v;
-      }
+    for (int i = 0; i < NWS; ++i) {
+      const int e = tid + i * 256;
+      const int q = e & 3, r = e >> 2;
+      const int co = r % (NT * 16), tl = r / (NT * 16);
+      int tap = grp * TG + tl;
+      tap = tap < KH * KW ? tap : KH * KW - 1;
+      const int c = c0 + q * 8;
+      const int cor = co0 + co < a.CoutP ? co0 + co : a.CoutP - 1;
+      wv[i] = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.CoutP + cor) * a.ldk + (c < a.ldk ? c : 0));
     }
+  };
+  auto write_w = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NWS; ++i) {
+      const int e = tid + i * 256;
+      const int q = e & 3, r = e >> 2;
+      const int co = r % (NT * 16), tl = r / (NT * 16);
+      const bool ok = c0 + q * 8 < a.ldk && co0 + co < a.CoutP;
+      if (e < TG * NT * 16 * 4) *reinterpret_cast<uint4*>(ws + (tl * NT * 16 + co) * HCKP + q * 8) = ok ? wv[i] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto load_x = [&](int c0) {
+    const bool second = a.x2 != nullptr && c0 >= a.csplit;
+    const zt_bf16* src = second ? a.x2 : a.x;
+    const int ld = second ? a.ldx2 : a.ldx;
+    const int cbase = second ? c0 - a.csplit : c0;
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      const int e = tid + i * 256;
+      const int p = e >> 2, q = e & 3;
+      int gy = gy0 + p / IC, gx = gx0 + p % IC;
+      gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+      gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+      const int c = cbase + q * 8;
+      xv[i] = *reinterpret_cast<const uint4*>(src + (size_t)((n * a.H + gy) * a.W + gx) * ld + (c < ld ? c : 0));
+    }
+  };
+  auto write_x = [&](int c0) {
+    const bool second = a.x2 != nullptr && c0 >= a.csplit;
+    const int cbase = second ? c0 - a.csplit : c0;
+    const int climit = second ? a.Cin - a.csplit : (a.x2 ? a.csplit : a.Cin);
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+      const int e = tid + i * 256;
+      const int p = e >> 2, q = e & 3;
+      const int gy = gy0 + p / IC, gx = gx0 + p % IC;
+      const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const int nv = climit - (cbase + q * 8);                  // valid channels of this 8-chunk (ragged tail / beyond the input)
+      const unsigned m0 = nv >= 2 ? ~0u : (nv == 1 ? 0xFFFFu : 0u), m1 = nv >= 4 ? ~0u : (nv == 3 ? 0xFFFFu : 0u);
+      const unsigned m2 = nv >= 6 ? ~0u : (nv == 5 ? 0xFFFFu : 0u), m3 = nv >= 8 ? ~0u : (nv == 7 ? 0xFFFFu : 0u);
+      uint4 v = xv[i];
+      v.x = in ? (v.x & m0) : 0u;
+      v.y = in ? (v.y & m1) : 0u;
+      v.z = in ? (v.z & m2) : 0u;
+      v.w = in ? (v.w & m3) : 0u;
+      if (e < IR * IC * 4) *reinterpret_cast<uint4*>(xs + p * HCKP + q * 8) = v;
+    }
+  };
+
+  load_x(0);
+  load_w(0, 0);
+  for (int c0 = 0; c0 < a.Cin; c0 += HCK) {
+    __syncthreads();
+    write_x(c0);
+    write_w(c0);
+    __syncthreads();
+    const bool more = c0 + HCK < a.Cin;
+    if (more) load_x(c0 + HCK);
+    if (ALL && more) load_w(c0 + HCK, 0);                       // single tap group: its weights are prefetched as well
 #pragma unroll 1
     for (int grp = 0; grp < NG; ++grp) {
-      if (grp > 0) __syncthreads();
-      if (grp > 0) load_w(grp);
-      write_w();
-      __syncthreads();
+      if (grp > 0) {                                            // per-kernel-row weight groups (7x7): staged inside the chunk
+        __syncthreads();
+        load_w(c0, grp);
+        write_w(c0);
+        __syncthreads();
+      }
 #pragma unroll
       for (int tl = 0; tl < TG; ++tl) {
         const int ky = ALL ? tl / KW : grp, kx = ALL ? tl % KW : tl;
@@ -506,6 +521,7 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
           for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(av[m], bv[q], acc[m][q]);
       }
     }
+    if (!ALL && more) load_w(c0 + HCK, 0);
   }
 
   const int oy = oy0 + wave;
