@@ -404,6 +404,32 @@ def test_conv_bf16(backend, case, variant):
         assert float(((gotg - refg).abs() - refg.abs() * 2 ** -8).max()) < 2e-3
 
 
+@pytest.mark.parametrize("case", [(3, 48, 1), (6, 48, 1), (3, 64, 2), (5, 48, 0)], ids=lambda c: "c%d-%d_epi%d" % c)
+def test_conv_bf16_thin_1x1(backend, case):
+    """Streaming 1x1 kernel for thin inputs (data gradient of the 48 -> 3 / 48 -> 6 output layers): transposed weights, LeakyReLU /
+    ReLU mask epilogue, NaN-filled padding lanes in the input buffer, ragged pixel count."""
+    import torch.nn.functional as F
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    Cin, Cout, epi = case
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    H, W = 37, 45
+    dz = torch.randn(1, Cin, H, W, generator=g).bfloat16().float()
+    w = torch.randn(Cin, Cout, 1, 1, generator=g) / Cout ** 0.5          # forward weight [Cout_fwd = Cin, Cin_fwd = Cout]
+    aux = torch.randn(1, Cout, H, W, generator=g).bfloat16().float()
+    ref = F.conv_transpose2d(dz, w.bfloat16().float())
+    if epi:
+        ref = ref * torch.where(aux > 0, 1.0, 0.2 if epi == 1 else 0.0)
+    xd = torch.full((1, H, W, 8), float("nan")).bfloat16()
+    xd[..., :Cin] = dz.permute(0, 2, 3, 1).bfloat16()
+    wt = ops.repack_weight_bf16(w.to(dev), transpose_flip=True)
+    y = ops.conv2d_bf16(CV(xd.to(dev), 0, Cin), wt, None, Cout, 1, 1, (0, 0), None, aux=_nhwc_bf16(aux, Cout).to(dev) if epi else None, epi=epi)
+    got = y.float().cpu()[..., :Cout].permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert float(((got - ref).abs() - ref.abs() * 2 ** -8).max()) < 1e-3
+
+
 @pytest.mark.parametrize("case", [(64, 64, "relu", 3), (64, 64, "relu", 0), (48, 48, "lrelu", 1), (9, 64, "relu", 0), (12, 48, "lrelu", 0), (3, 48, "lrelu", 2)], ids=lambda c: "c%d-%d_epi%d" % (c[0], c[1], c[3]))
 def test_conv_bf16_rs_pipeline(backend, case):
     """Register-stationary persistent kernel with several tiles per workgroup (> 256 tiles): exercises the double-buffered halo

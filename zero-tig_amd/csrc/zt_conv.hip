@@ -823,6 +823,53 @@ int launch_conv_ws(ConvArgsH& a, int NT, int CCH, int pth, hipStream_t stream) {
 #undef ZT_WS
 }
 
+// ---- 1x1 convolution with a thin input (Cin <= 8: the data gradient of Denoise_1/2's 48 -> 3 / 48 -> 6 output layers).
+// 2 * Cin FLOP per output element: a pure streaming kernel, no MFMA.  Thread = one cout octet x 4 pixels (weights for its 8
+// couts live in registers); load j of a wave covers 64 / (Cout/8) consecutive pixels; 16-byte loads and stores throughout.
+__global__ void __launch_bounds__(256) conv1x1_thin_bf16_kernel(ConvArgsH a, int npg) {
+  const int Q8 = a.Cout >> 3;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int o = (int)(i % Q8), pg = (int)(i / Q8);
+  if (pg >= npg) return;
+  const int HW = a.Ho * a.Wo;
+  float w[8][8], b[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    zt_ld8(a.w + (size_t)(o * 8 + c) * a.ldk, w[c]);            // [CoutP][ldk = 8], zero beyond Cin
+    b[c] = a.bias ? a.bias[o * 8 + c] : 0.f;
+  }
+  const float slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.2f);
+  const float neg = a.epi == 1 ? 0.2f : 0.f;
+  float x[4][8], u[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = min(pg + j * npg, HW - 1);
+    zt_ld8(a.x + (size_t)p * a.ldx, x[j]);
+    if (a.epi) zt_ld8(a.aux + (size_t)p * a.ldaux + o * 8, u[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)                                   // the buffer's padding lanes are not trusted (NaN * 0)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[j][k] = k < a.Cin ? x[j][k] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = pg + j * npg;
+    float r[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s = fmaf(w[c][k], x[j][k], s);
+      s = a.alpha * (s + b[c]);
+      s = fmaxf(s, slope * s);
+      if (a.epi == 3) s += u[j][c];
+      else if (a.epi) s *= (u[j][c] > 0.f ? 1.f : neg);
+      r[c] = s;
+    }
+    if (p < HW) zt_st8((zt_bf16*)a.y + (size_t)p * a.ldy + o * 8, r);
+  }
+}
+
 // ---- register-stationary persistent kernel for the full-resolution 3x3 layers (stride 1, bf16 nhwc output, 48 or 64 couts).
 // The LDS-fed kernels above are LDS-bandwidth bound (0.75 fragment reads per MFMA against the 0.5 that 128 B/clk sustains), so
 // here the WEIGHTS LIVE IN REGISTERS for the whole launch (one persistent workgroup per CU, <= 162 VGPRs of A fragments per
@@ -1454,6 +1501,15 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   // full-resolution stride-1 layers of the enhancement nets: persistent weight-stationary kernel
   const bool ws_ok = N == 1 && stride == 1 && KH == KW && (KH == 1 || KH == 3) && padH == KH / 2 && padW == KW / 2 && Cin <= 64 && !x2;
   ZT_REQUIRE(variant != 1 || ws_ok);
+  // thin-input 1x1 layers: streaming kernel
+  if (variant == 0 && N == 1 && KH == 1 && KW == 1 && stride == 1 && padH == 0 && padW == 0 && !x2 && Cin <= 8 && ldx == 8 && ldk == 8 &&
+      out_mode == 0 && act <= 2 && Cout % 8 == 0 && CoutP >= Cout && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
+      (!aux || (ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0))) {
+    const int npg = zt_cdiv(a.Ho * a.Wo, 4);
+    hipLaunchKernelGGL(conv1x1_thin_bf16_kernel, dim3((unsigned)zt_cdivl((long long)npg * (Cout / 8), 256)), dim3(256), 0, stream, a, npg);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+  }
   // register-stationary kernel: 3x3, bf16 nhwc output, 48 or 64 couts, input channels <= 16, 33..48 (Cout 48) or 49..64 (Cout 64)
   const bool rs_ok = ws_ok && KH == 3 && out_mode == 0 && act <= 2 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
                      (!aux || (ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0)) && ldx >= 8 &&
