@@ -45,24 +45,6 @@ struct Taps21 {
   float t[21];
 };
 
-template <bool VERT>
-__global__ void __launch_bounds__(256) blur_pass_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
-                                                        int H, int W, Taps21 k) {
-  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (x >= W || y >= H) return;
-  for (int c = 0; c < C; ++c) {
-    const float* p = src + (size_t)c * H * W;
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < 21; ++j) {
-      int yy = VERT ? zt_reflect(y + j - 10, H) : y;
-      int xx = VERT ? x : zt_reflect(x + j - 10, W);
-      acc = fmaf(k.t[j], p[(size_t)yy * W + xx], acc);
-    }
-    dst[(size_t)c * H * W + (size_t)y * W + x] = acc;
-  }
-}
-
 // adjoint of one reflect-padded pass: g_ext(u) = sum_j t_j * gy(u - j) on the extended domain, folded back
 template <bool VERT>
 __device__ __forceinline__ float blur_ext(const float* __restrict__ p, int fixed, int u, int n, int W, const Taps21& k) {
@@ -73,22 +55,6 @@ __device__ __forceinline__ float blur_ext(const float* __restrict__ p, int fixed
     if (i >= 0 && i < n) acc = fmaf(k.t[j], VERT ? p[(size_t)i * W + fixed] : p[(size_t)fixed * W + i], acc);
   }
   return acc;
-}
-
-template <bool VERT>
-__global__ void __launch_bounds__(256) blur_pass_adj_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                            int C, int H, int W, Taps21 k, int accumulate) {
-  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (x >= W || y >= H) return;
-  int n = VERT ? H : W, kk = VERT ? y : x, fixed = VERT ? x : y;
-  for (int c = 0; c < C; ++c) {
-    const float* p = src + (size_t)c * H * W;
-    float acc = blur_ext<VERT>(p, fixed, kk, n, W, k);
-    if (kk >= 1 && kk <= 10) acc += blur_ext<VERT>(p, fixed, -kk, n, W, k);
-    if (kk <= n - 2 && kk >= n - 11) acc += blur_ext<VERT>(p, fixed, 2 * (n - 1) - kk, n, W, k);
-    size_t o = (size_t)c * H * W + (size_t)y * W + x;
-    dst[o] = accumulate ? dst[o] + acc : acc;
-  }
 }
 
 // Vertical passes as a register sliding window: a thread owns one column and BRY consecutive output rows, loads the BRY + 20
@@ -118,14 +84,63 @@ __global__ void __launch_bounds__(256) blur_vert_kernel(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < 21; ++j) acc = fmaf(k.t[j], ADJ ? win[r + 20 - j] : win[r + j], acc);
       if (y < H) {
-        if (ADJ) {                                                                     // fold the reflected border back (rare rows)
-          if (y >= 1 && y <= 10) acc += blur_ext<true>(p, x, -y, H, W, k);
-          if (y <= H - 2 && y >= H - 11) acc += blur_ext<true>(p, x, 2 * (H - 1) - y, H, W, k);
-        }
         const size_t o = (size_t)c * H * W + (size_t)y * W + x;
         dst[o] = (ADJ && accumulate) ? dst[o] + acc : acc;
       }
     }
+  }
+}
+
+// Horizontal passes through an LDS row segment (256 outputs + 20 halo): one coalesced global load per input, 21 conflict-free
+// LDS reads per output; same fmaf order as the plain kernels.
+template <bool ADJ>
+__global__ void __launch_bounds__(256) blur_horz_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W,
+                                                        Taps21 k, int accumulate) {
+  __shared__ float buf[256 + 20];
+  const int x0 = blockIdx.x * 256, y = blockIdx.y, x = x0 + threadIdx.x;
+  for (int c = 0; c < C; ++c) {
+    const float* p = src + ((size_t)c * H + y) * W;
+    for (int i = threadIdx.x; i < 256 + 20; i += 256) {
+      const int gx = x0 - 10 + i;
+      if (ADJ) buf[i] = (gx >= 0 && gx < W) ? p[gx] : 0.f;
+      else buf[i] = p[zt_reflect(gx < W + 10 ? gx : W + 9, W)];
+    }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 21; ++j) acc = fmaf(k.t[j], ADJ ? buf[threadIdx.x + 20 - j] : buf[threadIdx.x + j], acc);
+    if (x < W) {
+      const size_t o = ((size_t)c * H + y) * W + x;
+      dst[o] = (ADJ && accumulate) ? dst[o] + acc : acc;
+    }
+    __syncthreads();
+  }
+}
+
+// second half of the horizontal adjoint: fold columns 1..10 and W-11..W-2, then (optionally) accumulate into the destination
+__global__ void __launch_bounds__(256) blur_horz_fold_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W,
+                                                             Taps21 k) {
+  const int y = blockIdx.x * 256 + threadIdx.x;
+  const bool left = blockIdx.y < 10;                            // W > 21: the two column groups are disjoint
+  const int x = left ? 1 + blockIdx.y : W - 11 + (blockIdx.y - 10);
+  if (y >= H) return;
+  for (int c = 0; c < C; ++c) {
+    const float* p = src + (size_t)c * H * W;
+    dst[(size_t)c * H * W + (size_t)y * W + x] += blur_ext<false>(p, y, left ? -x : 2 * (W - 1) - x, W, W, k);
+  }
+}
+
+// second half of the vertical adjoint: fold the reflected borders back into rows 1..10 and H-11..H-2 (20 rows only)
+__global__ void __launch_bounds__(256) blur_vert_fold_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W,
+                                                             Taps21 k) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const bool top = blockIdx.y < 10;                             // H > 21 (checked by the launcher): the two row groups are disjoint
+  const int y = top ? 1 + blockIdx.y : H - 11 + (blockIdx.y - 10);
+  if (x >= W) return;
+  for (int c = 0; c < C; ++c) {
+    const float* p = src + (size_t)c * H * W;
+    const size_t o = (size_t)c * H * W + (size_t)y * W + x;
+    dst[o] += blur_ext<true>(p, x, top ? -y : 2 * (H - 1) - y, H, W, k);
   }
 }
 
@@ -347,7 +362,7 @@ extern "C" int zt_blur21_f32(const float* src, float* tmp, float* dst, const flo
   ZT_REQUIRE(src && tmp && dst && taps21_host && H > 10 && W > 10);
   Taps21 k;
   for (int i = 0; i < 21; ++i) k.t[i] = taps21_host[i];
-  hipLaunchKernelGGL(blur_pass_kernel<false>, grid2d(W, H), dim3(64, 4), 0, stream, src, tmp, C, H, W, k);
+  hipLaunchKernelGGL(blur_horz_kernel<false>, dim3(zt_cdiv(W, 256), H), dim3(256), 0, stream, src, tmp, C, H, W, k, 0);
   hipLaunchKernelGGL(blur_vert_kernel<false>, dim3(zt_cdiv(W, 64), zt_cdiv(H, 4 * BRY)), dim3(64, 4), 0, stream, (const float*)tmp, dst, C, H, W, k, 0);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
@@ -359,7 +374,9 @@ extern "C" int zt_blur21_adj_f32(const float* g, float* tmp, float* dst, const f
   Taps21 k;
   for (int i = 0; i < 21; ++i) k.t[i] = taps21_host[i];
   hipLaunchKernelGGL(blur_vert_kernel<true>, dim3(zt_cdiv(W, 64), zt_cdiv(H, 4 * BRY)), dim3(64, 4), 0, stream, g, tmp, C, H, W, k, 0);
-  hipLaunchKernelGGL(blur_pass_adj_kernel<false>, grid2d(W, H), dim3(64, 4), 0, stream, (const float*)tmp, dst, C, H, W, k, accumulate);
+  hipLaunchKernelGGL(blur_vert_fold_kernel, dim3(zt_cdiv(W, 256), 20), dim3(256), 0, stream, g, tmp, C, H, W, k);
+  hipLaunchKernelGGL(blur_horz_kernel<true>, dim3(zt_cdiv(W, 256), H), dim3(256), 0, stream, (const float*)tmp, dst, C, H, W, k, accumulate);
+  hipLaunchKernelGGL(blur_horz_fold_kernel, dim3(zt_cdiv(H, 256), 20), dim3(256), 0, stream, (const float*)tmp, dst, C, H, W, k);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
