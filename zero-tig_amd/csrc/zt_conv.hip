@@ -934,7 +934,19 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
       }
     }
 
-  const int n_my = blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8, so within every round of gridDim tiles XCD x takes the x-th run of
+  // gridDim / 8 consecutive indices, and indices walk the image in bands of 4 tile rows, column-major inside a band: an XCD's
+  // 32 tiles of a round form an 8 x 4 block whose interior halos are shared in that XCD's L2 instead of re-fetched from HBM.
+  const int G = gridDim.x;
+  const int pb = (G % 8 == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+  const int n_my = pb < ntiles ? (ntiles - 1 - pb) / G + 1 : 0;
+  auto tile_xy = [&](int k, int& ty, int& tx) {
+    const int idx = pb + k * G;
+    const int band = idx / (4 * a.tilesX), r = idx - band * 4 * a.tilesX;
+    const int rows = a.tilesY - band * 4 < 4 ? a.tilesY - band * 4 : 4;
+    tx = r / rows;
+    ty = band * 4 + r - tx * rows;
+  };
 
   // halo slot e = tid + 512 i -> pixel e / NCHK (row-major in the IR x IC halo), chunk e % NCHK == tid % NCHK for every i
   uint4 pf[NPF];
@@ -943,8 +955,9 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
   // LDS-DMA form: wave-instruction (8 i + wave) fills positions [64 (8 i + wave), +64) of the linear image; position e holds
   // pixel e / 8, logical chunk (e % 8) ^ (column & 7) -- the swizzle is applied to the source address.  Needs Cin % 8 == 0.
   auto glds_halo = [&](int k) {
-    const int tile = blockIdx.x + k * gridDim.x;
-    const int gy0 = (tile / a.tilesX) * RTH - 1, gx0 = (tile % a.tilesX) * TW - 1;
+    int ty, tx;
+    tile_xy(k, ty, tx);
+    const int gy0 = ty * RTH - 1, gx0 = tx * TW - 1;
     zt_bf16* xb = xs[k & 1];
     int ln = lane;
     ZT_OPAQUE(ln);                                              // recompute the slot geometry per tile instead of keeping it in registers
@@ -967,8 +980,9 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
       glds_halo(k);
       return;
     }
-    const int tile = blockIdx.x + k * gridDim.x;
-    const int gy0 = (tile / a.tilesX) * RTH - 1, gx0 = (tile % a.tilesX) * TW - 1;
+    int ty, tx;
+    tile_xy(k, ty, tx);
+    const int gy0 = ty * RTH - 1, gx0 = tx * TW - 1;
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       const int p = (tid + i * 512) / NCHK;
@@ -980,8 +994,9 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
   };
   auto write_halo = [&](int k) {
     if constexpr (GLDS) return;
-    const int tile = blockIdx.x + k * gridDim.x;
-    const int gy0 = (tile / a.tilesX) * RTH - 1, gx0 = (tile % a.tilesX) * TW - 1;
+    int ty, tx;
+    tile_xy(k, ty, tx);
+    const int gy0 = ty * RTH - 1, gx0 = tx * TW - 1;
     const int nv = a.Cin - hq * 8;                              // valid channels of this thread's chunk: padding lanes are not trusted
     const unsigned k0 = nv >= 2 ? ~0u : (nv == 1 ? 0xFFFFu : 0u), k1 = nv >= 4 ? ~0u : (nv == 3 ? 0xFFFFu : 0u);
     const unsigned k2 = nv >= 6 ? ~0u : (nv == 5 ? 0xFFFFu : 0u), k3 = nv >= 8 ? ~0u : (nv == 7 ? 0xFFFFu : 0u);
@@ -1004,8 +1019,9 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
   // EPI: the aux tile (activation mask / residual) is DMA'd into the staging buffer that is idle during this tile's MFMA loop;
   // chunk e is fetched by the very lane that consumes it (e = 64 (8 i + wave) + lane), so only that lane's vmcnt matters.
   auto glds_aux = [&](int k, int buf) {
-    const int tile = blockIdx.x + k * gridDim.x;
-    const int oy0 = (tile / a.tilesX) * RTH, ox0 = (tile % a.tilesX) * TW;
+    int ty, tx;
+    tile_xy(k, ty, tx);
+    const int oy0 = ty * RTH, ox0 = tx * TW;
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
       const int e = tid + i * 512, pl = e / CH8, ch = e % CH8;
@@ -1016,8 +1032,9 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
     }
   };
   auto store_tile = [&](int k) {
-    const int tile = blockIdx.x + k * gridDim.x;
-    const int oy0 = (tile / a.tilesX) * RTH, ox0 = (tile % a.tilesX) * TW;
+    int ty, tx;
+    tile_xy(k, ty, tx);
+    const int oy0 = ty * RTH, ox0 = tx * TW;
     const zt_bf16* sb = st[k & 1];
     const zt_bf16* ab = st[(k + 1) & 1];
     const float neg = a.epi == 1 ? 0.2f : 0.f;
@@ -1082,7 +1099,7 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
 #pragma unroll
       for (int m = 0; m < NM; ++m)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[r][m][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NQ; ++q) acc[r][m][q] = *reinterpret_cast<const zt_f32x4*>(&bias_s[(q0 + q) * 16 + l4 * 4]);   // bias
 
     if (EPI) {
       if (k >= 1) glds_aux(k - 1, k & 1);
@@ -1144,13 +1161,16 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int cb = (q0 + q) * 16 + l4 * 4;
-          const float4 bq = *reinterpret_cast<const float4*>(&bias_s[cb]);
-          const float bj[4] = {bq.x, bq.y, bq.z, bq.w};
           float v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[j] = a.alpha * (acc[r][m][q][j] + bj[j]);
-            v[j] = fmaxf(v[j], slope * v[j]);
+          for (int j = 0; j < 4; ++j) v[j] = acc[r][m][q][j];
+          if (a.alpha != 1.f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= a.alpha;
+          }
+          if (a.act) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], slope * v[j]);
           }
           uint2 pk;
           pk.x = zt_f2bf2(v[0], v[1]);
