@@ -806,9 +806,8 @@ int launch_conv_ws(ConvArgsH& a, int NT, int CCH, int pth, hipStream_t stream) {
   per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
   int gx = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
   dim3 grid(gx, (c16 + NT - 1) / NT), block(64 * pth);
-#define ZT_WS(nt, cch)                                                                                                   \
-  if (pth == 8) hipLaunchKernelGGL((conv_ws_bf16_kernel<K, nt, cch, 8>), grid, block, 0, stream, a, ntiles);            \
-  else hipLaunchKernelGGL((conv_ws_bf16_kernel<K, nt, cch, 4>), grid, block, 0, stream, a, ntiles);                     \
+#define ZT_WS(nt, cch)                                                                               \
+  hipLaunchKernelGGL((conv_ws_bf16_kernel<K, nt, cch, 8>), grid, block, 0, stream, a, ntiles);      \
   return 0
   if (CCH == 1) {
     if (NT == 1) { ZT_WS(1, 1); }
@@ -1545,14 +1544,8 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   if (variant != 2 && ws_ok && (variant == 1 || (long long)zt_cdiv(a.Wo, TW) * zt_cdiv(a.Ho, 8) >= 1024)) {
     a.tilesX = zt_cdiv(a.Wo, TW);
     int CCH = Cin <= 32 ? 1 : 2;
-    int pth = 8, nt = NT;
-    const char* cfg = getenv("ZT_WS_CFG");          // tuning hook: "<rows><nt>", e.g. "42" = 4-row tiles, 32 couts per workgroup
-    if (cfg && cfg[0] && cfg[1]) {
-      pth = cfg[0] == '4' ? 4 : 8;
-      int want = cfg[1] - '0';
-      if (want >= 1 && want <= 4 && want <= NT) nt = want;
-    }
-    int rcw = (KH == 3) ? launch_conv_ws<3>(a, nt, CCH, pth, stream) : launch_conv_ws<1>(a, nt, CCH, pth, stream);
+    // 8-row tiles, all couts per workgroup: the best of the (rows, couts) configurations measured
+    int rcw = (KH == 3) ? launch_conv_ws<3>(a, NT, CCH, 8, stream) : launch_conv_ws<1>(a, NT, CCH, 8, stream);
     if (rcw) return rcw;
     ZT_LAUNCH_CHECK();
     return ZT_OK;

@@ -95,12 +95,6 @@ class Engine:
             self.sv[key] = (u, a1, a2, cin)
         return r
 
-    def _bias_grad(self, dz, cout, name):
-        o = self.ops
-        part = o.chan_stats(dz)
-        nblk, C = part.shape[1], part.shape[3]
-        o.partial_reduce(part, nblk, 2 * C, cout, out=self.g[name], accumulate=True)
-
     def _denoise_bwd(self, pre, key, dr, cout, want_input_grad):
         """dr: NHWC gradient of the 1x1 output (first `cout` channels valid).  Accumulates parameter grads; returns the planar
         [1,cin,H,W] gradient of the packed input when requested."""
