@@ -1257,21 +1257,8 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
     v.w = in ? (v.w & m3) : 0u;
     return v;
   };
-  // XCD-aware banded tile order (as conv_rs): indices walk bands of 4 tile rows column-major, workgroup b (XCD b % 8) starts
-  // at the (b % 8)-th run of gridDim / 8 indices, so the tiles an XCD works on at a time are 2-D neighbours sharing halos in L2
-  const int G = gridDim.x;
-  const int pb = (G % 8 == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
-  const int tilesY = a.ntiles / a.tilesX;
-  auto tile_xy = [&](int idx, int& ty, int& tx) {
-    const int band = idx / (4 * a.tilesX), r = idx - band * 4 * a.tilesX;
-    const int rows = tilesY - band * 4 < 4 ? tilesY - band * 4 : 4;
-    tx = r / rows;
-    ty = band * 4 + r - tx * rows;
-  };
   auto load_tile = [&](int tile) {
-    int ty, tx;
-    tile_xy(tile, ty, tx);
-    const int oy0 = ty * HTH, ox0 = tx * HTW;
+    const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
       const int e = tid + i * NTHR;
@@ -1294,9 +1281,7 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
     }
   };
   auto write_tile = [&](int tile) {
-    int ty, tx;
-    tile_xy(tile, ty, tx);
-    const int oy0 = ty * HTH, ox0 = tx * HTW;
+    const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
       const int e = tid + i * NTHR;
@@ -1315,8 +1300,8 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
     }
   };
 
-  if (pb < a.ntiles) load_tile(pb);
-  for (int tile = pb; tile < a.ntiles; tile += gridDim.x) {
+  if ((int)blockIdx.x < a.ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();
     write_tile(tile);
     __syncthreads();
