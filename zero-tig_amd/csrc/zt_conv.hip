@@ -391,18 +391,21 @@ struct ConvArgsH {
   int tilesX, tilesY;
 };
 
-constexpr int HCK = 32, HCKP = 48;      // 96-byte rows: conflict-free ds_read_b128 for every lane group and pixel shift
+constexpr int HCK = 32;                 // channel granularity of a two-part (split) input
 
-// ALL: every tap's weights of the current 32-channel chunk fit in LDS next to the input tile -> 2 barriers per chunk;
+// ALL: every tap's weights of the current channel chunk fit in LDS next to the input tile -> 2 barriers per chunk;
 // otherwise weights are staged per kernel row (7x7).  MT = 16-pixel MFMA tiles per wave along x (1 for small feature maps).
-template <int KH, int KW, int S, int NT, int MT, bool ALL>
+// CH2 = 32-channel MFMA K-steps per staged chunk: 2 (64 channels, 160-byte rows) halves the barrier / staging rounds of the
+// latency-bound small-map layers whose Cin is a multiple of 64.
+template <int KH, int KW, int S, int NT, int MT, bool ALL, int CH2>
 __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
+  constexpr int KCH = 32 * CH2, KCHP = CH2 == 2 ? 80 : 48, CPP = 4 * CH2;      // channels / LDS pitch / 16-byte chunks per pixel
   constexpr int TWm = 16 * MT;
   constexpr int IR = (TH - 1) * S + KH, IC = (TWm - 1) * S + KW;
   constexpr int TG = ALL ? KH * KW : KW;          // taps staged together
   constexpr int NG = ALL ? 1 : KH;
-  __shared__ __attribute__((aligned(16))) zt_bf16 xs[IR * IC * HCKP];
-  __shared__ __attribute__((aligned(16))) zt_bf16 ws[TG * NT * 16 * HCKP];
+  __shared__ __attribute__((aligned(16))) zt_bf16 xs[IR * IC * KCHP];
+  __shared__ __attribute__((aligned(16))) zt_bf16 ws[TG * NT * 16 * KCHP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int t = blockIdx.x;
@@ -424,14 +427,14 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
   // global -> registers -> LDS, software-pipelined over the 32-channel chunks: all loads of a chunk are issued together
   // (clamped addresses, no branches; borders and ragged channel tails are masked when written) and the NEXT chunk's loads are
   // issued before this chunk's MFMAs, so one global latency is exposed per launch rather than several per chunk.
-  constexpr int NWS = (TG * NT * 16 * 4 + 255) / 256;
-  constexpr int NXS = (IR * IC * 4 + 255) / 256;
+  constexpr int NWS = (TG * NT * 16 * CPP + 255) / 256;
+  constexpr int NXS = (IR * IC * CPP + 255) / 256;
   uint4 wv[NWS], xv[NXS];
   auto load_w = [&](int c0, int grp) {
 #pragma unroll
     for (int i = 0; i < NWS; ++i) {
       const int e = tid + i * 256;
-      const int q = e & 3, r = e >> 2;
+      const int q = e % CPP, r = e / CPP;
       const int co = r % (NT * 16), tl = r / (NT * 16);
       int tap = grp * TG + tl;
       tap = tap < KH * KW ? tap : KH * KW - 1;
@@ -444,10 +447,10 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
 #pragma unroll
     for (int i = 0; i < NWS; ++i) {
       const int e = tid + i * 256;
-      const int q = e & 3, r = e >> 2;
+      const int q = e % CPP, r = e / CPP;
       const int co = r % (NT * 16), tl = r / (NT * 16);
       const bool ok = c0 + q * 8 < a.ldk && co0 + co < a.CoutP;
-      if (e < TG * NT * 16 * 4) *reinterpret_cast<uint4*>(ws + (tl * NT * 16 + co) * HCKP + q * 8) = ok ? wv[i] : make_uint4(0u, 0u, 0u, 0u);
+      if (e < TG * NT * 16 * CPP) *reinterpret_cast<uint4*>(ws + (tl * NT * 16 + co) * KCHP + q * 8) = ok ? wv[i] : make_uint4(0u, 0u, 0u, 0u);
     }
   };
   auto load_x = [&](int c0) {
@@ -458,7 +461,7 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
       const int e = tid + i * 256;
-      const int p = e >> 2, q = e & 3;
+      const int p = e / CPP, q = e % CPP;
       int gy = gy0 + p / IC, gx = gx0 + p % IC;
       gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
       gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
@@ -473,7 +476,7 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
       const int e = tid + i * 256;
-      const int p = e >> 2, q = e & 3;
+      const int p = e / CPP, q = e % CPP;
       const int gy = gy0 + p / IC, gx = gx0 + p % IC;
       const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       const int nv = climit - (cbase + q * 8);                  // valid channels of this 8-chunk (ragged tail / beyond the input)
@@ -484,20 +487,20 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
       v.y = in ? (v.y & m1) : 0u;
       v.z = in ? (v.z & m2) : 0u;
       v.w = in ? (v.w & m3) : 0u;
-      if (e < IR * IC * 4) *reinterpret_cast<uint4*>(xs + p * HCKP + q * 8) = v;
+      if (e < IR * IC * CPP) *reinterpret_cast<uint4*>(xs + p * KCHP + q * 8) = v;
     }
   };
 
   load_x(0);
   load_w(0, 0);
-  for (int c0 = 0; c0 < a.Cin; c0 += HCK) {
+  for (int c0 = 0; c0 < a.Cin; c0 += KCH) {
     __syncthreads();
     write_x(c0);
     write_w(c0);
     __syncthreads();
-    const bool more = c0 + HCK < a.Cin;
-    if (more) load_x(c0 + HCK);
-    if (ALL && more) load_w(c0 + HCK, 0);                       // single tap group: its weights are prefetched as well
+    const bool more = c0 + KCH < a.Cin;
+    if (more) load_x(c0 + KCH);
+    if (ALL && more) load_w(c0 + KCH, 0);                       // single tap group: its weights are prefetched as well
 #pragma unroll 1
     for (int grp = 0; grp < NG; ++grp) {
       if (grp > 0) {                                            // per-kernel-row weight groups (7x7): staged inside the chunk
@@ -509,19 +512,23 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
 #pragma unroll
       for (int tl = 0; tl < TG; ++tl) {
         const int ky = ALL ? tl / KW : grp, kx = ALL ? tl % KW : tl;
-        zt_s16x8 av[MT], bv[NT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-          av[m] = *reinterpret_cast<const zt_s16x8*>(xs + ((wave * S + ky) * IC + (m * 16 + l15) * S + kx) * HCKP + 8 * l4);
+        for (int kc = 0; kc < CH2; ++kc) {
+          zt_s16x8 av[MT], bv[NT];
 #pragma unroll
-        for (int q = 0; q < NT; ++q) bv[q] = *reinterpret_cast<const zt_s16x8*>(ws + (tl * NT * 16 + q * 16 + l15) * HCKP + 8 * l4);
+          for (int m = 0; m < MT; ++m)
+            av[m] = *reinterpret_cast<const zt_s16x8*>(xs + ((wave * S + ky) * IC + (m * 16 + l15) * S + kx) * KCHP + kc * 32 + 8 * l4);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int q = 0; q < NT; ++q)
+            bv[q] = *reinterpret_cast<const zt_s16x8*>(ws + (tl * NT * 16 + q * 16 + l15) * KCHP + kc * 32 + 8 * l4);
 #pragma unroll
-          for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(av[m], bv[q], acc[m][q]);
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(av[m], bv[q], acc[m][q]);
+        }
       }
     }
-    if (!ALL && more) load_w(c0 + HCK, 0);
+    if (!ALL && more) load_w(c0 + KCH, 0);
   }
 
   const int oy = oy0 + wave;
@@ -559,10 +566,20 @@ int launch_conv_h(const ConvArgsH& a, int NT, unsigned gx, hipStream_t stream) {
   int c16 = (a.Cout + 15) / 16;
   dim3 grid(gx, (c16 + NT - 1) / NT);
   constexpr int IRc = (TH - 1) * S + KH, ICc = (16 * MT - 1) * S + KW;
+  // 64-channel chunks where every chunk is full: Cin (and the split point of a two-part input) multiples of 64
+  const bool wide = a.Cin % 64 == 0 && (!a.x2 || a.csplit % 64 == 0);
 #define ZT_CH(nt)                                                                                             \
   {                                                                                                           \
-    constexpr bool all = (KH * KW * nt * 16 + IRc * ICc) * HCKP * 2 <= 72 * 1024;                             \
-    hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all>), grid, block, 0, stream, a);           \
+    constexpr bool all1 = (KH * KW * nt * 16 + IRc * ICc) * 48 * 2 <= 72 * 1024;                              \
+    constexpr bool all2 = (KH * KW * nt * 16 + IRc * ICc) * 80 * 2 <= 150 * 1024;                             \
+    constexpr bool fits2 = ((all2 ? KH * KW : KW) * nt * 16 + IRc * ICc) * 80 * 2 <= 150 * 1024;              \
+    if constexpr (fits2) {                                                                                    \
+      if (wide) {                                                                                             \
+        hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all2, 2>), grid, block, 0, stream, a);   \
+        break;                                                                                                \
+      }                                                                                                       \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all1, 1>), grid, block, 0, stream, a);       \
   }
   switch (NT) {
     case 1: ZT_CH(1) break;
