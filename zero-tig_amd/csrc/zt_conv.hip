@@ -571,8 +571,8 @@ int launch_conv_h(const ConvArgsH& a, int NT, unsigned gx, hipStream_t stream) {
 #define ZT_CH(nt)                                                                                             \
   {                                                                                                           \
     constexpr bool all1 = (KH * KW * nt * 16 + IRc * ICc) * 48 * 2 <= 72 * 1024;                              \
-    constexpr bool all2 = (KH * KW * nt * 16 + IRc * ICc) * 80 * 2 <= 150 * 1024;                             \
-    constexpr bool fits2 = ((all2 ? KH * KW : KW) * nt * 16 + IRc * ICc) * 80 * 2 <= 150 * 1024;              \
+    constexpr bool all2 = (KH * KW * nt * 16 + IRc * ICc) * 80 * 2 <= 64 * 1024;                              \
+    constexpr bool fits2 = all2;              /* only while >= 2 workgroups still fit a CU: larger tiles lose more than they gain */ \
     if constexpr (fits2) {                                                                                    \
       if (wide) {                                                                                             \
         hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all2, 2>), grid, block, 0, stream, a);   \
