@@ -1234,12 +1234,12 @@ struct WgradArgsH {
   int tilesX, ntiles;
 };
 
-constexpr int HTH = 4, HTW = 32;
+constexpr int HTW = 32;                 // tile = HTH rows x 32 pixels; HTH = 2 * NW (4 or 8): 8-wave workgroups keep twice the bytes in flight
 
 // NW waves per workgroup share the (tap, ci-tile) pairs; 8 for the 64x64 layer so that accumulators + staging registers stay <= 128
 template <int KH, int KW, int CT, int NT, int NW>
 __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) {
-  constexpr int NTHR = NW * 64;
+  constexpr int NTHR = NW * 64, HTH = NW;
   constexpr int IR = HTH + KH - 1, IC = HTW + KW - 1;
   constexpr int CIP = CT * 16 + 8, COP = NT * 16 + 8;
   constexpr int NPAIR = KH * KW * CT;
@@ -1598,7 +1598,7 @@ extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
   a.x = (const zt_bf16*)x; a.dz = (const zt_bf16*)dz; a.slab = slab; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.Cout = Cout;
   a.lddz = lddz;
   a.tilesX = zt_cdiv(W, HTW);
-  a.ntiles = a.tilesX * zt_cdiv(H, HTH);
+  a.ntiles = a.tilesX * zt_cdiv(H, (CT == 4 && NT == 4) ? 8 : 4);      // tile rows = waves of the variant (launch_wgrad_h)
   size_t per = ((size_t)KH * KW * CT * 16 * NT * 16 + NT * 16) * sizeof(float);
   int want = 512;
   if (const char* e = getenv("ZT_WGRAD_BLOCKS")) want = atoi(e) > 0 ? atoi(e) : want;      // tuning hook

@@ -57,17 +57,10 @@ class Lib:
             self.fns[name] = fn
         self.calls = {}
 
-    @staticmethod
-    def _conv(a):
-        if a is None:
-            return None
-        if isinstance(a, torch.Tensor):
-            return a.data_ptr()
-        return a
-
     def call(self, name, *args):
-        fn = self.fns[name]
-        rc = fn(*[self._conv(a) for a in args])
+        """Launch one entry point.  Tensors are passed as their device pointers; everything else goes through ctypes as is."""
+        T = torch.Tensor
+        rc = self.fns[name](*[a.data_ptr() if isinstance(a, T) else a for a in args])
         self.calls[name] = self.calls.get(name, 0) + 1
         if rc != 0:
             raise RuntimeError("%s failed with code %d%s" % (name, rc, " (invalid argument)" if rc == 1001 else " (hipError_t)"))
@@ -87,6 +80,8 @@ def get_lib():
 
 
 def current_stream(device):
+    """Raw hipStream_t of torch's current stream on `device` (None = default stream of the test emulator's CPU tensors)."""
     if device.type == "cuda":
-        return torch.cuda.current_stream(device).cuda_stream
+        idx = device.index
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
     return None
