@@ -31,7 +31,14 @@ def run(cin, cout, k, variant, epi=0, iters=10):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+AB_MODE = os.environ.get("ZT_BENCH_AB")
 names = {3: "register-stationary", 33: "rs no-mfma", 34: "rs no-store", 36: "rs no-halo", 38: "rs mfma only", 39: "rs barriers only", 1: "ws full", 2: "tiled"}
+if AB_MODE:      # A/B of two variants, interleaved, many iterations: ZT_BENCH_AB="3,40"
+    va, vb = (int(t) for t in AB_MODE.split(","))
+    for (cin, cout) in ((64, 64), (48, 48)):
+        for rep in range(3):
+            print("c%d->%d  variant %d: %7.1f us   variant %d: %7.1f us" % (cin, cout, va, run(cin, cout, 3, va, iters=60), vb, run(cin, cout, 3, vb, iters=60)), flush=True)
+    sys.exit(0)
 for (cin, cout, k) in ((64, 64, 3), (48, 48, 3)):
     for v in (3, 33, 34, 36, 38, 39, 1):
         print("c%d->%d k%d  %-24s %8.1f us" % (cin, cout, k, names[v], run(cin, cout, k, v)), flush=True)
