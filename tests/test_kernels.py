@@ -364,7 +364,7 @@ BF16_CONV = [(3, 48, 3, 8, "lrelu"), (48, 48, 3, 48, "lrelu"), (64, 64, 3, 64, "
              (48, 6, 1, 48, None), (9, 64, 3, 16, "relu"), (12, 48, 3, 16, None)]
 
 
-@pytest.mark.parametrize("variant", [2, 1, 3], ids=["tiled", "ws", "rs"])
+@pytest.mark.parametrize("variant", [2, 1, 3, 0], ids=["tiled", "ws", "rs", "auto"])
 @pytest.mark.parametrize("case", BF16_CONV, ids=lambda c: "c%d-%d_k%d" % c[:3])
 def test_conv_bf16(backend, case, variant):
     import torch.nn.functional as F

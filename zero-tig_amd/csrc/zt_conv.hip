@@ -886,6 +886,33 @@ __global__ void __launch_bounds__(256) conv1x1_thin_bf16_kernel(ConvArgsH a, int
   }
 }
 
+// ---- 1x1 convolution with a thin fp32 planar output (Cout <= 8: the 48 -> 3 / 48 -> 6 output layers of Denoise_1/2).  Streaming:
+// thread = one pixel, reads its Cin/8 16-byte chunks (a wave reads one contiguous span), weights are wave-uniform (scalar
+// loads), each output plane is written coalesced.
+template <int CO>
+__global__ void __launch_bounds__(256) conv1x1_thinout_bf16_kernel(ConvArgsH a) {
+  const int HW = a.Ho * a.Wo;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  for (int c8 = 0; c8 < a.Cin; c8 += 8) {
+    float x[8];
+    zt_ld8(a.x + (size_t)p * a.ldx + c8, x);
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      float w[8];
+      zt_ld8(a.w + (size_t)c * a.ldk + c8, w);                  // uniform address: scalar loads
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[c] = fmaf(w[k], (c8 + k < a.Cin) ? x[k] : 0.f, acc[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CO; ++c)
+    if (c < a.Cout) ((float*)a.y)[(size_t)c * a.ldy + p] = apply_act(a.alpha * (acc[c] + (a.bias ? a.bias[c] : 0.f)), a.act);
+}
+
 // ---- register-stationary persistent kernel for the full-resolution 3x3 layers (stride 1, bf16 nhwc output, 48 or 64 couts).
 // The LDS-fed kernels above are LDS-bandwidth bound (0.75 fragment reads per MFMA against the 0.5 that 128 B/clk sustains), so
 // here the WEIGHTS LIVE IN REGISTERS for the whole launch (one persistent workgroup per CU, <= 162 VGPRs of A fragments per
@@ -1537,6 +1564,15 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   // full-resolution stride-1 layers of the enhancement nets: persistent weight-stationary kernel
   const bool ws_ok = N == 1 && stride == 1 && KH == KW && (KH == 1 || KH == 3) && padH == KH / 2 && padW == KW / 2 && Cin <= 64 && !x2;
   ZT_REQUIRE(variant != 1 || ws_ok);
+  // thin-output 1x1 layers with planar fp32 output: streaming kernel
+  if (variant == 0 && N == 1 && KH == 1 && KW == 1 && stride == 1 && padH == 0 && padW == 0 && !x2 && Cout <= 8 && out_mode == 1 &&
+      epi == 0 && Cin % 8 == 0 && ldk >= Cin && CoutP >= Cout) {
+    const unsigned nb = (unsigned)zt_cdiv(a.Ho * a.Wo, 256);
+    if (Cout <= 4) hipLaunchKernelGGL(conv1x1_thinout_bf16_kernel<4>, dim3(nb), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(conv1x1_thinout_bf16_kernel<8>, dim3(nb), dim3(256), 0, stream, a);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+  }
   // thin-input 1x1 layers: streaming kernel
   if (variant == 0 && N == 1 && KH == 1 && KW == 1 && stride == 1 && padH == 0 && padW == 0 && !x2 && Cin <= 8 && ldx == 8 && ldk == 8 &&
       out_mode == 0 && act <= 2 && Cout % 8 == 0 && CoutP >= Cout && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
