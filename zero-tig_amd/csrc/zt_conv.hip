@@ -897,15 +897,26 @@ __global__ void __launch_bounds__(256) conv1x1_thinout_bf16_kernel(ConvArgsH a) 
   float acc[CO];
 #pragma unroll
   for (int c = 0; c < CO; ++c) acc[c] = 0.f;
-  for (int c8 = 0; c8 < a.Cin; c8 += 8) {
-    float x[8];
-    zt_ld8(a.x + (size_t)p * a.ldx + c8, x);
+  uint4 xv[8];                                                  // Cin <= 64: all of the pixel's loads in flight together
 #pragma unroll
-    for (int c = 0; c < CO; ++c) {
-      float w[8];
-      zt_ld8(a.w + (size_t)c * a.ldk + c8, w);                  // uniform address: scalar loads
+  for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const uint4*>(a.x + (size_t)p * a.ldx + (i * 8 < a.Cin ? i * 8 : 0));
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc[c] = fmaf(w[k], (c8 + k < a.Cin) ? x[k] : 0.f, acc[c]);
+  for (int i = 0; i < 8; ++i) {
+    if (i * 8 < a.Cin) {                                        // uniform
+      const unsigned xw[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[2 * j] = zt_u2f(xw[j] << 16);
+        x[2 * j + 1] = zt_u2f(xw[j] & 0xFFFF0000u);
+      }
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        float w[8];
+        zt_ld8(a.w + (size_t)c * a.ldk + i * 8, w);             // uniform address: scalar loads
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[c] = fmaf(w[k], x[k], acc[c]);
+      }
     }
   }
 #pragma unroll
@@ -1566,7 +1577,7 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   ZT_REQUIRE(variant != 1 || ws_ok);
   // thin-output 1x1 layers with planar fp32 output: streaming kernel
   if (variant == 0 && N == 1 && KH == 1 && KW == 1 && stride == 1 && padH == 0 && padW == 0 && !x2 && Cout <= 8 && out_mode == 1 &&
-      epi == 0 && Cin % 8 == 0 && ldk >= Cin && CoutP >= Cout) {
+      epi == 0 && Cin % 8 == 0 && Cin <= 64 && ldk >= Cin && CoutP >= Cout) {
     const unsigned nb = (unsigned)zt_cdiv(a.Ho * a.Wo, 256);
     if (Cout <= 4) hipLaunchKernelGGL(conv1x1_thinout_bf16_kernel<4>, dim3(nb), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(conv1x1_thinout_bf16_kernel<8>, dim3(nb), dim3(256), 0, stream, a);
