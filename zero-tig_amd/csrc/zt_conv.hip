@@ -994,12 +994,30 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
   const int G = gridDim.x;
   const int pb = (G % 8 == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
   const int n_my = pb < ntiles ? (ntiles - 1 - pb) / G + 1 : 0;
-  auto tile_xy = [&](int k, int& ty, int& tx) {
+  // the (ty, tx) of this workgroup's k-th tile: computed once into a small LDS table (the divisions are ~40 instructions and
+  // three phases per tile need the coordinates), recomputed only beyond the table
+  constexpr int TTAB = 256;
+  __shared__ int tile_s[TTAB];
+  auto tile_calc = [&](int k, int& ty, int& tx) {
     const int idx = pb + k * G;
     const int band = idx / (4 * a.tilesX), r = idx - band * 4 * a.tilesX;
     const int rows = a.tilesY - band * 4 < 4 ? a.tilesY - band * 4 : 4;
     tx = r / rows;
     ty = band * 4 + r - tx * rows;
+  };
+  for (int k = tid; k < n_my && k < TTAB; k += 512) {
+    int ty, tx;
+    tile_calc(k, ty, tx);
+    tile_s[k] = (ty << 16) | tx;
+  }
+  auto tile_xy = [&](int k, int& ty, int& tx) {
+    if (k < TTAB) {
+      const int v = __builtin_amdgcn_readfirstlane(tile_s[k]);
+      ty = v >> 16;
+      tx = v & 0xFFFF;
+    } else {
+      tile_calc(k, ty, tx);
+    }
   };
 
   // halo slot e = tid + 512 i -> pixel e / NCHK (row-major in the IR x IC halo), chunk e % NCHK == tid % NCHK for every i
@@ -1008,11 +1026,36 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
   const int hq8 = hq * 8 + 8 <= a.ldx ? hq * 8 : a.ldx - 8;     // never read past the pixel's channels; masked below
   // LDS-DMA form: wave-instruction (8 i + wave) fills positions [64 (8 i + wave), +64) of the linear image; position e holds
   // pixel e / 8, logical chunk (e % 8) ^ (column & 7) -- the swizzle is applied to the source address.  Needs Cin % 8 == 0.
+  // Interior tiles (the halo lies inside the image: ~95 % of them) take a precomputed per-slot offset relative to the tile
+  // origin -- one add per DMA; border tiles recompute the clamped / zero-filled addresses.  The offsets cost NGL registers,
+  // which the EPI instantiations do not have: they always take the general path.
+  constexpr bool FASTSLOT = GLDS && !EPI;
+  int soff[FASTSLOT ? NGL : 1];
+  if constexpr (FASTSLOT) {
+#pragma unroll
+    for (int i = 0; i < NGL; ++i) {
+      const int e = (i * 8 + wave) * 64 + lane;
+      const int p = e >> 3, col = p % IC;
+      const int cj = (e & 7) ^ (col & 7);
+      soff[i] = cj * 8 < a.Cin ? ((p / IC) * a.W + col) * a.ldx + cj * 8 : -1;       // -1: channel chunk beyond Cin -> zeros
+    }
+  }
   auto glds_halo = [&](int k) {
     int ty, tx;
     tile_xy(k, ty, tx);
     const int gy0 = ty * RTH - 1, gx0 = tx * TW - 1;
     zt_bf16* xb = xs[k & 1];
+    if constexpr (FASTSLOT) {
+      if (gy0 >= 0 && gy0 + IR <= a.H && gx0 >= 0 && gx0 + IC <= a.W) {
+        const zt_bf16* base = a.x + (unsigned)((gy0 * a.W + gx0) * a.ldx);
+#pragma unroll
+        for (int i = 0; i < NGL; ++i) {
+          const void* src = soff[i] >= 0 ? (const void*)(base + soff[i]) : (const void*)&zt_zero_chunk;
+          if (i * 512 + 511 < IR * IC * 8 || (i * 8 + wave) * 64 + lane < IR * IC * 8) zt_glds16(src, xb + (i * 8 + wave) * 512);
+        }
+        return;
+      }
+    }
     int ln = lane;
     ZT_OPAQUE(ln);                                              // recompute the slot geometry per tile instead of keeping it in registers
 #pragma unroll
@@ -1128,6 +1171,7 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
     }
   };
 
+  __syncthreads();                                              // tile table and bias visible
   if (n_my > 0) {
     load_halo(0);
     write_halo(0);
