@@ -167,11 +167,23 @@ __device__ __forceinline__ void zt_glds16(const void* gsrc, void* lds_wave_base)
 
 // s_waitcnt vmcnt(0) only (gfx9 encoding: vmcnt = simm16[15:14|3:0], expcnt [6:4] and lgkmcnt [11:8] left at their maxima)
 __device__ __forceinline__ void zt_wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// s_waitcnt vmcnt(N), N < 16: all but the N most recently issued vector-memory operations have completed (in-order counter)
+template <int N>
+__device__ __forceinline__ void zt_wait_vmcnt() {
+  static_assert(N >= 0 && N < 16, "vmcnt immediate");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | N);
+}
 
 // make a value opaque to the optimiser (keeps per-iteration address arithmetic from being hoisted out of a persistent loop and
 // spilled).  The host-side test emulator pre-defines it as a no-op.
 #ifndef ZT_OPAQUE
 #define ZT_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain vmcnt, so LDS-DMA / global loads
+// issued before it stay in flight across it.  The host-side test emulator pre-defines it as __syncthreads().
+#ifndef ZT_LDS_BARRIER
+#define ZT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
 // compile-time counted loop: f(std::integral_constant<int, I>) for I in [B, E)

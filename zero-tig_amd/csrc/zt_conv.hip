@@ -1128,14 +1128,17 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
       zt_glds16(a.aux + (unsigned)((oy * a.Wo + ox) * a.ldaux + ch * 8), st[buf] + (i * 8 + wave) * 512);
     }
   };
-  auto store_tile = [&](int k) {
+  auto store_tile = [&](int k, bool halo_in_flight = false) {
     int ty, tx;
     tile_xy(k, ty, tx);
     const int oy0 = ty * RTH, ox0 = tx * TW;
     const zt_bf16* sb = st[k & 1];
     const zt_bf16* ab = st[(k + 1) & 1];
     const float neg = a.epi == 1 ? 0.2f : 0.f;
-    if (EPI) zt_wait_vmcnt0();                                  // this lane's aux DMA has landed
+    if (EPI) {                                                  // this lane's aux DMA has landed; the halo DMAs issued after it may still fly
+      if (halo_in_flight) zt_wait_vmcnt<GLDS ? NGL : NPF>();
+      else zt_wait_vmcnt0();
+    }
     uint4 v[NOUT];
     if (!EPI) {                                                 // EPI runs mid-loop with every accumulator live: one chunk at a time
 #pragma unroll
@@ -1243,8 +1246,8 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (EPI && step == NSTEP / 2 - 1) {             // aux has had half of the loop to arrive
-        if (k >= 1) store_tile(k - 1);
-        __syncthreads();                                        // aux consumed: the rest of the loop may end in staging writes to that buffer
+        if (k >= 1) store_tile(k - 1, k + 1 < n_my);
+        ZT_LDS_BARRIER();                                       // aux consumed (LDS reads only: the halo DMAs keep flying): the rest of the loop may end in staging writes to that buffer
       }
     });
 #undef ZT_LOADX
