@@ -1361,7 +1361,9 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
   };
   // interior tiles with full channel chunks (the common case) use per-slot offsets relative to the tile origin, computed once:
   // one add per load and no masks; border tiles / ragged channels take the general path
-  int xoff[NXL], zoff[NZL];
+  constexpr bool FAST = CT >= 3 && NT >= 3;                     // the wide layers only: thin ones never have full channel chunks
+  int xoff[FAST ? NXL : 1], zoff[FAST ? NZL : 1];
+  if constexpr (FAST) {
 #pragma unroll
   for (int i = 0; i < NXL; ++i) {
     const int e = tid + i * NTHR < IR * IC * CT * 2 ? tid + i * NTHR : 0;
@@ -1372,7 +1374,8 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
     const int e = tid + i * NTHR < HTH * HTW * NT * 2 ? tid + i * NTHR : 0;
     zoff[i] = (((e / (NT * 2)) / HTW) * a.W + (e / (NT * 2)) % HTW) * a.lddz + (e % (NT * 2)) * 8;
   }
-  const bool full_ch = a.Cin == CT * 16 && a.Cout == NT * 16;
+  }
+  const bool full_ch = FAST && a.Cin == CT * 16 && a.Cout == NT * 16;
   auto interior = [&](int tile) {
     const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
     return full_ch && oy0 - padH >= 0 && oy0 - padH + IR <= a.H && ox0 - padW >= 0 && ox0 - padW + IC <= a.W && oy0 + HTH <= a.H &&
@@ -1380,7 +1383,7 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
   };
   auto load_tile = [&](int tile) {
     const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
-    if (interior(tile)) {
+    if constexpr (FAST) if (interior(tile)) {
       const zt_bf16* xb = a.x + (unsigned)(((oy0 - padH) * a.W + ox0 - padW) * a.ldx);
       const zt_bf16* zb = a.dz + (unsigned)((oy0 * a.W + ox0) * a.lddz);
 #pragma unroll
@@ -1412,7 +1415,7 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
   };
   auto write_tile = [&](int tile) {
     const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
-    if (interior(tile)) {
+    if constexpr (FAST) if (interior(tile)) {
 #pragma unroll
       for (int i = 0; i < NXL; ++i) {
         const int e = tid + i * NTHR;
