@@ -1359,39 +1359,8 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
     v.w = in ? (v.w & m3) : 0u;
     return v;
   };
-  // interior tiles with full channel chunks (the common case) use per-slot offsets relative to the tile origin, computed once:
-  // one add per load and no masks; border tiles / ragged channels take the general path
-  constexpr bool FAST = CT >= 3 && NT >= 3;                     // the wide layers only: thin ones never have full channel chunks
-  int xoff[FAST ? NXL : 1], zoff[FAST ? NZL : 1];
-  if constexpr (FAST) {
-#pragma unroll
-  for (int i = 0; i < NXL; ++i) {
-    const int e = tid + i * NTHR < IR * IC * CT * 2 ? tid + i * NTHR : 0;
-    xoff[i] = (((e / (CT * 2)) / IC) * a.W + (e / (CT * 2)) % IC) * a.ldx + (e % (CT * 2)) * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < NZL; ++i) {
-    const int e = tid + i * NTHR < HTH * HTW * NT * 2 ? tid + i * NTHR : 0;
-    zoff[i] = (((e / (NT * 2)) / HTW) * a.W + (e / (NT * 2)) % HTW) * a.lddz + (e % (NT * 2)) * 8;
-  }
-  }
-  const bool full_ch = FAST && a.Cin == CT * 16 && a.Cout == NT * 16;
-  auto interior = [&](int tile) {
-    const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
-    return full_ch && oy0 - padH >= 0 && oy0 - padH + IR <= a.H && ox0 - padW >= 0 && ox0 - padW + IC <= a.W && oy0 + HTH <= a.H &&
-           ox0 + HTW <= a.W;
-  };
   auto load_tile = [&](int tile) {
     const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
-    if constexpr (FAST) if (interior(tile)) {
-      const zt_bf16* xb = a.x + (unsigned)(((oy0 - padH) * a.W + ox0 - padW) * a.ldx);
-      const zt_bf16* zb = a.dz + (unsigned)((oy0 * a.W + ox0) * a.lddz);
-#pragma unroll
-      for (int i = 0; i < NXL; ++i) px[i] = *reinterpret_cast<const uint4*>(xb + xoff[i]);
-#pragma unroll
-      for (int i = 0; i < NZL; ++i) pz[i] = *reinterpret_cast<const uint4*>(zb + zoff[i]);
-      return;
-    }
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
       const int e = tid + i * NTHR;
@@ -1415,19 +1384,6 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
   };
   auto write_tile = [&](int tile) {
     const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
-    if constexpr (FAST) if (interior(tile)) {
-#pragma unroll
-      for (int i = 0; i < NXL; ++i) {
-        const int e = tid + i * NTHR;
-        if (e < IR * IC * CT * 2) *reinterpret_cast<uint4*>(xs + (e / (CT * 2)) * CIP + (e % (CT * 2)) * 8) = px[i];
-      }
-#pragma unroll
-      for (int i = 0; i < NZL; ++i) {
-        const int e = tid + i * NTHR;
-        if (e < HTH * HTW * NT * 2) *reinterpret_cast<uint4*>(zs + (e / (NT * 2)) * COP + (e % (NT * 2)) * 8) = pz[i];
-      }
-      return;
-    }
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
       const int e = tid + i * NTHR;
