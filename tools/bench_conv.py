@@ -33,6 +33,12 @@ def run(cin, cout, k, variant, epi=0, iters=10):
 
 AB_MODE = os.environ.get("ZT_BENCH_AB")
 names = {3: "register-stationary", 33: "rs no-mfma", 34: "rs no-store", 36: "rs no-halo", 38: "rs mfma only", 39: "rs barriers only", 1: "ws full", 2: "tiled"}
+ABL = os.environ.get("ZT_BENCH_ABL")
+if ABL:           # phase ablations of the register-stationary kernel on one layer: ZT_BENCH_ABL="9,64"
+    cin, cout = (int(t) for t in ABL.split(","))
+    for v in (3, 33, 34, 36, 38, 39):
+        print("c%d->%d  %-22s %7.1f us" % (cin, cout, names[v], run(cin, cout, 3, v, iters=30)), flush=True)
+    sys.exit(0)
 if AB_MODE:      # A/B of two variants, interleaved, many iterations: ZT_BENCH_AB="3,40"
     va, vb = (int(t) for t in AB_MODE.split(","))
     for (cin, cout) in ((64, 64), (48, 48)):

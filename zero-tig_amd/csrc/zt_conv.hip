@@ -1313,9 +1313,11 @@ int launch_conv_rs(ConvArgsH& a, hipStream_t stream) {
     return 0;                                                                                                                \
   }
   if (a.Cout == 64 && kc == 2) ZT_RS(2, 2, true, 2, 0)
-  if (a.Cout == 64 && kc == 0) ZT_RS(2, 2, true, 0, 1)
+  // thin inputs: ONE zero-padded K=32 chunk, not a K=16 one -- v_mfma_f32_16x16x16_bf16 runs at a quarter of the K=32
+  // instruction's FLOP rate on gfx950 (measured: 32 vs 16 cycles), so padding to 32 channels halves the MFMA time
+  if (a.Cout == 64 && kc == 0) ZT_RS(2, 2, true, 1, 0)
   if (a.Cout == 48 && kc == 1) ZT_RS(3, 1, false, 1, 1)
-  if (a.Cout == 48 && kc == 0) ZT_RS(3, 1, false, 0, 1)
+  if (a.Cout == 48 && kc == 0) ZT_RS(3, 1, false, 1, 0)
 #undef ZT_RS
   return ZT_EINVAL;
 }
