@@ -1178,7 +1178,6 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
   if (n_my > 0) {
     load_halo(0);
     write_halo(0);
-    if (!GLDS && n_my > 1) load_halo(1);                        // register path: tile k+1 is written to LDS at the START of tile k
   }
   __syncthreads();
 
@@ -1203,23 +1202,11 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[r][m][q] = *reinterpret_cast<const zt_f32x4*>(&bias_s[(q0 + q) * 16 + l4 * 4]);   // bias
 
-    // halo of the next tile.  LDS-DMA path: issue the DMAs for tile k+1 now, they land during this tile's MFMA loop.  Register
-    // path (thin inputs: the MFMA loop is too short to cover a memory latency): the registers hold tile k+1, loaded one whole
-    // tile ago -- write it to the other LDS buffer (free since the barrier that ended tile k-1) and start loading tile k+2.
-    auto next_halo = [&]() {
-      if (a.dbg & 4) return;
-      if constexpr (GLDS) {
-        if (k + 1 < n_my) load_halo(k + 1);
-      } else {
-        if (k + 1 < n_my) write_halo(k + 1);
-        if (k + 2 < n_my) load_halo(k + 2);
-      }
-    };
     if (EPI) {
       if (k >= 1) glds_aux(k - 1, k & 1);
-      next_halo();
+      if (k + 1 < n_my && !(a.dbg & 4)) load_halo(k + 1);
     } else {
-      next_halo();
+      if (k + 1 < n_my && !(a.dbg & 4)) load_halo(k + 1);
       if (k >= 1 && !(a.dbg & 2)) store_tile(k - 1);
     }
 
@@ -1259,11 +1246,12 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (EPI && step == NSTEP / 2 - 1) {             // aux has had half of the loop to arrive
-        if (k >= 1) store_tile(k - 1, GLDS ? k + 1 < n_my : k + 2 < n_my);
+        if (k >= 1) store_tile(k - 1, k + 1 < n_my);
         ZT_LDS_BARRIER();                                       // aux consumed (LDS reads only: the halo DMAs keep flying): the rest of the loop may end in staging writes to that buffer
       }
     });
 #undef ZT_LOADX
+    if (k + 1 < n_my) write_halo(k + 1);
 
     // accumulators -> staging (bias, alpha, activation, bf16): lane holds couts 4 l4 .. +3 of 16-cout block q for pixel l15
     zt_bf16* sb = st[k & 1];
@@ -1313,11 +1301,9 @@ int launch_conv_rs(ConvArgsH& a, hipStream_t stream) {
     return 0;                                                                                                                \
   }
   if (a.Cout == 64 && kc == 2) ZT_RS(2, 2, true, 2, 0)
-  // thin inputs: ONE zero-padded K=32 chunk, not a K=16 one -- v_mfma_f32_16x16x16_bf16 runs at a quarter of the K=32
-  // instruction's FLOP rate on gfx950 (measured: 32 vs 16 cycles), so padding to 32 channels halves the MFMA time
-  if (a.Cout == 64 && kc == 0) ZT_RS(2, 2, true, 1, 0)
+  if (a.Cout == 64 && kc == 0) ZT_RS(2, 2, true, 0, 1)
   if (a.Cout == 48 && kc == 1) ZT_RS(3, 1, false, 1, 1)
-  if (a.Cout == 48 && kc == 0) ZT_RS(3, 1, false, 1, 0)
+  if (a.Cout == 48 && kc == 0) ZT_RS(3, 1, false, 0, 1)
 #undef ZT_RS
   return ZT_EINVAL;
 }
