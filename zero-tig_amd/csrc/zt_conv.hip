@@ -933,7 +933,6 @@ __global__ void __launch_bounds__(256) conv1x1_thinout_bf16_kernel(ConvArgsH a) 
 // staging (tile k-1's 16-byte global stores, with the fused mask / residual epilogue, are issued inside tile k's MFMA loop).
 // One barrier per tile.  128-byte pixel rows are XOR-swizzled by (halo column & 7): conflict-free ds_read_b128 for every tap.
 // Channel tails use the K=16 MFMA (48 = 32 + 16, and the thin 3/9/12-channel inputs are a single K=16 chunk).
-constexpr int RTH = 8;
 __device__ const uint4 zt_zero_chunk = {0u, 0u, 0u, 0u};        // LDS-DMA source of the halo's out-of-image pixels
 
 __device__ __forceinline__ zt_f32x4 zt_mfma_bf16_k16(zt_s16x4 a, zt_s16x4 b, zt_f32x4 c) {
@@ -943,23 +942,28 @@ __device__ __forceinline__ zt_f32x4 zt_mfma_bf16_k16(zt_s16x4 a, zt_s16x4 b, zt_
 
 // wave w of 8: row pair w >> 1; COSPLIT: couts [NQ*16*(w&1), +NQ*16) of 2*NQ*16, both 16-pixel halves (NM == 2)
 //                               else   : all NQ*16 couts, 16-pixel half (w & 1) (NM == 1)
-template <int NQ, int NM, bool COSPLIT, int C32, int C16, bool EPI>
-__global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntiles) {
+// RT = tile rows = waves per workgroup: 8 (one workgroup per CU, double-buffered staging) or 4 (two independent workgroups per
+// CU, single staging buffer: one workgroup's epilogue / barrier / DMA issue overlaps the other's MFMA loop; not for EPI, whose
+// aux operand needs the second staging buffer)
+template <int NQ, int NM, bool COSPLIT, int C32, int C16, bool EPI, int RT>
+__global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(ConvArgsH a, int ntiles) {
+  constexpr int RTH = RT, NTHR = 64 * RT, NST = RT == 8 ? 2 : 1;
+  static_assert(RT == 8 || !EPI, "the 4-row variant has no second staging buffer for the aux operand");
   constexpr int IR = RTH + 2, IC = TW + 2;
   constexpr int KC = C32 * 32 + C16 * 16;                       // input channels staged per pixel
   constexpr int PE = KC > 32 ? 64 : (KC > 16 ? 32 : 16);        // LDS elements per pixel; only the 128-byte rows need the swizzle
   constexpr bool SWZ = PE == 64;
   constexpr int NCHK = PE / 8;                                  // 16-byte chunks per pixel
   constexpr bool GLDS = PE == 64;                               // full 128-byte rows go global -> LDS by DMA: no staging registers
-  constexpr int NPF = GLDS ? 1 : (IR * IC * NCHK + 511) / 512;
-  constexpr int NGL = (IR * IC * 8 + 511) / 512;                // LDS-DMA wave-instructions per wave and tile
+  constexpr int NPF = GLDS ? 1 : (IR * IC * NCHK + NTHR - 1) / NTHR;
+  constexpr int NGL = (IR * IC * 8 + NTHR - 1) / NTHR;                // LDS-DMA wave-instructions per wave and tile
   constexpr int CW = (COSPLIT ? 2 : 1) * NQ * 16;               // couts of the layer (== a.Cout)
   constexpr int CH8 = CW / 8;
   constexpr bool SWZO = CW == 64;
-  constexpr int NOUT = RTH * TW * CH8 / 512;
-  static_assert(RTH * TW * CH8 % 512 == 0 && 512 % NCHK == 0, "tile geometry");
+  constexpr int NOUT = RTH * TW * CH8 / NTHR;
+  static_assert(RTH * TW * CH8 % NTHR == 0 && NTHR % NCHK == 0, "tile geometry");
   __shared__ __attribute__((aligned(16))) zt_bf16 xs[2][IR * IC * PE];
-  __shared__ __attribute__((aligned(16))) zt_bf16 st[2][RTH * TW * CW];
+  __shared__ __attribute__((aligned(16))) zt_bf16 st[NST][RTH * TW * CW];
   __shared__ float bias_s[CW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1005,7 +1009,7 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
     tx = r / rows;
     ty = band * 4 + r - tx * rows;
   };
-  for (int k = tid; k < n_my && k < TTAB; k += 512) {
+  for (int k = tid; k < n_my && k < TTAB; k += NTHR) {
     int ty, tx;
     tile_calc(k, ty, tx);
     tile_s[k] = (ty << 16) | tx;
@@ -1034,7 +1038,7 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
   if constexpr (FASTSLOT) {
 #pragma unroll
     for (int i = 0; i < NGL; ++i) {
-      const int e = (i * 8 + wave) * 64 + lane;
+      const int e = (i * RT + wave) * 64 + lane;
       const int p = e >> 3, col = p % IC;
       const int cj = (e & 7) ^ (col & 7);
       soff[i] = cj * 8 < a.Cin ? ((p / IC) * a.W + col) * a.ldx + cj * 8 : -1;       // -1: channel chunk beyond Cin -> zeros
@@ -1051,7 +1055,7 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
 #pragma unroll
         for (int i = 0; i < NGL; ++i) {
           const void* src = soff[i] >= 0 ? (const void*)(base + soff[i]) : (const void*)&zt_zero_chunk;
-          if (i * 512 + 511 < IR * IC * 8 || (i * 8 + wave) * 64 + lane < IR * IC * 8) zt_glds16(src, xb + (i * 8 + wave) * 512);
+          if (i * NTHR + NTHR - 1 < IR * IC * 8 || (i * RT + wave) * 64 + lane < IR * IC * 8) zt_glds16(src, xb + (i * RT + wave) * 512);
         }
         return;
       }
@@ -1060,7 +1064,7 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
     ZT_OPAQUE(ln);                                              // recompute the slot geometry per tile instead of keeping it in registers
 #pragma unroll
     for (int i = 0; i < NGL; ++i) {
-      const int e = (i * 8 + wave) * 64 + ln;
+      const int e = (i * RT + wave) * 64 + ln;
       const int p = e >> 3, col = p % IC;
       const int cj = (e & 7) ^ (col & 7);
       const int gy = gy0 + p / IC, gx = gx0 + col;
@@ -1069,7 +1073,7 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
       const int cc = cj * 8 + 8 <= a.ldx ? cj * 8 : 0;
       const zt_bf16* s1 = a.x + (unsigned)((gyc * a.W + gxc) * a.ldx + cc);
       const void* src = in ? (const void*)s1 : (const void*)&zt_zero_chunk;
-      if (i * 512 + 511 < IR * IC * 8 || e < IR * IC * 8) zt_glds16(src, xb + (i * 8 + wave) * 512);
+      if (i * NTHR + NTHR - 1 < IR * IC * 8 || e < IR * IC * 8) zt_glds16(src, xb + (i * RT + wave) * 512);
     }
   };
   auto load_halo = [&](int k) {
@@ -1082,7 +1086,7 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
     const int gy0 = ty * RTH - 1, gx0 = tx * TW - 1;
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      const int p = (tid + i * 512) / NCHK;
+      const int p = (tid + i * NTHR) / NCHK;
       int gy = gy0 + p / IC, gx = gx0 + p % IC;                 // out-of-image slots read a clamped address, zeroed when written
       gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
       gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
@@ -1100,7 +1104,7 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
     zt_bf16* xb = xs[k & 1];
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      const int e = tid + i * 512, p = e / NCHK, col = p % IC;
+      const int e = tid + i * NTHR, p = e / NCHK, col = p % IC;
       const int gy = gy0 + p / IC, gx = gx0 + col;
       const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       uint4 v = pf[i];
@@ -1121,19 +1125,19 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
     const int oy0 = ty * RTH, ox0 = tx * TW;
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
-      const int e = tid + i * 512, pl = e / CH8, ch = e % CH8;
+      const int e = tid + i * NTHR, pl = e / CH8, ch = e % CH8;
       int oy = oy0 + pl / TW, ox = ox0 + pl % TW;
       oy = oy >= a.Ho ? a.Ho - 1 : oy;
       ox = ox >= a.Wo ? a.Wo - 1 : ox;
-      zt_glds16(a.aux + (unsigned)((oy * a.Wo + ox) * a.ldaux + ch * 8), st[buf] + (i * 8 + wave) * 512);
+      zt_glds16(a.aux + (unsigned)((oy * a.Wo + ox) * a.ldaux + ch * 8), st[buf] + (i * RT + wave) * 512);
     }
   };
   auto store_tile = [&](int k, bool halo_in_flight = false) {
     int ty, tx;
     tile_xy(k, ty, tx);
     const int oy0 = ty * RTH, ox0 = tx * TW;
-    const zt_bf16* sb = st[k & 1];
-    const zt_bf16* ab = st[(k + 1) & 1];
+    const zt_bf16* sb = st[k & (NST - 1)];
+    const zt_bf16* ab = st[(k + 1) & (NST - 1)];
     const float neg = a.epi == 1 ? 0.2f : 0.f;
     if (EPI) {                                                  // this lane's aux DMA has landed; the halo DMAs issued after it may still fly
       if (halo_in_flight) zt_wait_vmcnt<GLDS ? NGL : NPF>();
@@ -1143,13 +1147,13 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
     if (!EPI) {                                                 // EPI runs mid-loop with every accumulator live: one chunk at a time
 #pragma unroll
       for (int i = 0; i < NOUT; ++i) {
-        const int e = tid + i * 512, pl = e / CH8, ch = e % CH8;
+        const int e = tid + i * NTHR, pl = e / CH8, ch = e % CH8;
         v[i] = *reinterpret_cast<const uint4*>(sb + pl * CW + ((SWZO ? (ch ^ (pl & 7)) : ch) * 8));
       }
     }
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
-      const int e = tid + i * 512, pl = e / CH8, ch = e % CH8;
+      const int e = tid + i * NTHR, pl = e / CH8, ch = e % CH8;
       const int oy = oy0 + pl / TW, ox = ox0 + pl % TW;
       uint4 o;
       if (EPI) {
@@ -1208,6 +1212,7 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
     } else {
       if (k + 1 < n_my && !(a.dbg & 4)) load_halo(k + 1);
       if (k >= 1 && !(a.dbg & 2)) store_tile(k - 1);
+      if constexpr (NST == 1) ZT_LDS_BARRIER();                 // single staging buffer: every wave has read tile k-1 before tile k is staged
     }
 
     // steps: halo row h (0..3) x kx x channel chunk; each step's fragments serve output rows r with ky = h - r in [0, 2]
@@ -1254,7 +1259,7 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
     if (k + 1 < n_my) write_halo(k + 1);
 
     // accumulators -> staging (bias, alpha, activation, bf16): lane holds couts 4 l4 .. +3 of 16-cout block q for pixel l15
-    zt_bf16* sb = st[k & 1];
+    zt_bf16* sb = st[k & (NST - 1)];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -1289,16 +1294,21 @@ __global__ void __launch_bounds__(512) conv_rs_bf16_kernel(ConvArgsH a, int ntil
 }
 
 int launch_conv_rs(ConvArgsH& a, hipStream_t stream) {
+  // forward layers (no fused aux operand): two 4-wave workgroups per CU on 4-row tiles; EPI layers: one 8-wave workgroup
+  static const int rt4 = getenv("ZT_CONV_RS4") ? atoi(getenv("ZT_CONV_RS4")) : 1;
+  const int rt = (!a.epi && rt4) ? 4 : 8;
   a.tilesX = zt_cdiv(a.Wo, TW);
-  a.tilesY = zt_cdiv(a.Ho, RTH);
+  a.tilesY = zt_cdiv(a.Ho, rt);
   const int ntiles = a.tilesX * a.tilesY;
-  dim3 grid(ntiles < 256 ? ntiles : 256), block(512);
+  const int maxg = rt == 4 ? 512 : 256;
+  dim3 grid(ntiles < maxg ? ntiles : maxg), block(64 * rt);
   const int kc = a.Cin <= 16 ? 0 : (a.Cin > 48 ? 2 : 1);       // 0: one K=16 chunk, 1: 32 + 16, 2: 32 + 32
-#define ZT_RS(nq, nm, cs, c32, c16)                                                                                          \
-  {                                                                                                                          \
-    if (a.epi) hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, true>), grid, block, 0, stream, a, ntiles);      \
-    else hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, false>), grid, block, 0, stream, a, ntiles);           \
-    return 0;                                                                                                                \
+#define ZT_RS(nq, nm, cs, c32, c16)                                                                                            \
+  {                                                                                                                            \
+    if (a.epi) hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, true, 8>), grid, block, 0, stream, a, ntiles);     \
+    else if (rt == 4) hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, false, 4>), grid, block, 0, stream, a, ntiles); \
+    else hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, false, 8>), grid, block, 0, stream, a, ntiles);          \
+    return 0;                                                                                                                  \
   }
   if (a.Cout == 64 && kc == 2) ZT_RS(2, 2, true, 2, 0)
   if (a.Cout == 64 && kc == 0) ZT_RS(2, 2, true, 0, 1)
@@ -1646,7 +1656,7 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
                      ((Cout == 64 && (Cin <= 16 || Cin == 56 || Cin == 64)) || (Cout == 48 && (Cin <= 16 || Cin == 40 || Cin == 48)));
   ZT_REQUIRE(variant != 3 || rs_ok);
   static const int rs_auto = getenv("ZT_CONV_RS") ? atoi(getenv("ZT_CONV_RS")) : 1;
-  if (rs_ok && (variant == 3 || (variant == 0 && rs_auto && (long long)zt_cdiv(a.Wo, TW) * zt_cdiv(a.Ho, RTH) >= 1024))) {
+  if (rs_ok && (variant == 3 || (variant == 0 && rs_auto && (long long)zt_cdiv(a.Wo, TW) * zt_cdiv(a.Ho, 8) >= 1024))) {
     int rcp = launch_conv_rs(a, stream);
     if (rcp) return rcp;
     ZT_LAUNCH_CHECK();
