@@ -28,6 +28,17 @@ def test_header_symbols_exported_by_hip_library():
     assert {s for s in exported if s.startswith("zt_")} == set(lib.protos), "exported zt_* symbols must all be declared in the header"
 
 
+def test_integration_doc_names_exist_in_header():
+    """INTEGRATION.md's entry-point table must not drift from include/zerotig_hip.h."""
+    import re
+    from importlib import import_module
+    lib_mod = import_module("zero-tig_amd.lib")
+    declared = set(lib_mod.parse_header())
+    doc = open(os.path.join(lib_mod.ROOT, "INTEGRATION.md")).read()
+    named = set(re.findall(r"`(zt_\w+)`", doc))
+    assert named and named <= declared, sorted(named - declared)
+
+
 def test_product_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
