@@ -948,7 +948,9 @@ __device__ __forceinline__ zt_f32x4 zt_mfma_bf16_k16(zt_s16x4 a, zt_s16x4 b, zt_
 template <int NQ, int NM, bool COSPLIT, int C32, int C16, bool EPI, int RT>
 __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(ConvArgsH a, int ntiles) {
   constexpr int RTH = RT, NTHR = 64 * RT, NST = RT == 8 ? 2 : 1;
-  static_assert(RT == 8 || !EPI, "the 4-row variant has no second staging buffer for the aux operand");
+  // fused aux operand (activation mask / residual): the 8-row form DMAs its tile into the idle staging buffer (AUXL); the 4-row
+  // form has no second staging buffer and reads it in accumulator layout (8 bytes per lane and 16x16 block) half a loop ahead
+  constexpr bool AUXL = EPI && RT == 8, AUXD = EPI && RT == 4;
   constexpr int IR = RTH + 2, IC = TW + 2;
   constexpr int KC = C32 * 32 + C16 * 16;                       // input channels staged per pixel
   constexpr int PE = KC > 32 ? 64 : (KC > 16 ? 32 : 16);        // LDS elements per pixel; only the 128-byte rows need the swizzle
@@ -1139,12 +1141,12 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
     const zt_bf16* sb = st[k & (NST - 1)];
     const zt_bf16* ab = st[(k + 1) & (NST - 1)];
     const float neg = a.epi == 1 ? 0.2f : 0.f;
-    if (EPI) {                                                  // this lane's aux DMA has landed; the halo DMAs issued after it may still fly
+    if (AUXL) {                                                 // this lane's aux DMA has landed; the halo DMAs issued after it may still fly
       if (halo_in_flight) zt_wait_vmcnt<GLDS ? NGL : NPF>();
       else zt_wait_vmcnt0();
     }
     uint4 v[NOUT];
-    if (!EPI) {                                                 // EPI runs mid-loop with every accumulator live: one chunk at a time
+    if (!AUXL) {                                                // AUXL runs mid-loop with every accumulator live: one chunk at a time
 #pragma unroll
       for (int i = 0; i < NOUT; ++i) {
         const int e = tid + i * NTHR, pl = e / CH8, ch = e % CH8;
@@ -1156,7 +1158,7 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
       const int e = tid + i * NTHR, pl = e / CH8, ch = e % CH8;
       const int oy = oy0 + pl / TW, ox = ox0 + pl % TW;
       uint4 o;
-      if (EPI) {
+      if (AUXL) {
         o = *reinterpret_cast<const uint4*>(sb + pl * CW + ((SWZO ? (ch ^ (pl & 7)) : ch) * 8));
         const uint4 u = *reinterpret_cast<const uint4*>(ab + e * 8);
         const unsigned vv[4] = {o.x, o.y, o.z, o.w}, uu[4] = {u.x, u.y, u.z, u.w};
@@ -1206,7 +1208,7 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[r][m][q] = *reinterpret_cast<const zt_f32x4*>(&bias_s[(q0 + q) * 16 + l4 * 4]);   // bias
 
-    if (EPI) {
+    if (AUXL) {
       if (k >= 1) glds_aux(k - 1, k & 1);
       if (k + 1 < n_my && !(a.dbg & 4)) load_halo(k + 1);
     } else {
@@ -1214,6 +1216,7 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
       if (k >= 1 && !(a.dbg & 2)) store_tile(k - 1);
       if constexpr (NST == 1) ZT_LDS_BARRIER();                 // single staging buffer: every wave has read tile k-1 before tile k is staged
     }
+    uint2 au[AUXD ? 2 : 1][AUXD ? NM : 1][AUXD ? NQ : 1];       // AUXD: this lane's aux values, in accumulator layout
 
     // steps: halo row h (0..3) x kx x channel chunk; each step's fragments serve output rows r with ky = h - r in [0, 2]
     constexpr int NCK = C32 + C16;
@@ -1250,7 +1253,22 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (EPI && step == NSTEP / 2 - 1) {             // aux has had half of the loop to arrive
+      if constexpr (AUXD && step == NSTEP / 2 - 1) {            // aux in accumulator layout: half a loop of latency cover
+        int ty, tx;
+        tile_xy(k, ty, tx);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int m = 0; m < NM; ++m) {
+            int oy = ty * RTH + 2 * rp + r, ox = tx * TW + (m0 + m) * 16 + l15;
+            oy = oy >= a.Ho ? a.Ho - 1 : oy;
+            ox = ox >= a.Wo ? a.Wo - 1 : ox;
+            const zt_bf16* ap = a.aux + (unsigned)((oy * a.Wo + ox) * a.ldaux + q0 * 16 + l4 * 4);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) au[AUXD ? r : 0][AUXD ? m : 0][AUXD ? q : 0] = *reinterpret_cast<const uint2*>(ap + q * 16);
+          }
+      }
+      if constexpr (AUXL && step == NSTEP / 2 - 1) {            // aux has had half of the loop to arrive
         if (k >= 1) store_tile(k - 1, k + 1 < n_my);
         ZT_LDS_BARRIER();                                       // aux consumed (LDS reads only: the halo DMAs keep flying): the rest of the loop may end in staging writes to that buffer
       }
@@ -1278,6 +1296,13 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], slope * v[j]);
           }
+          if constexpr (AUXD) {                                 // fused epilogue on the fp32 values: one rounding
+            const uint2 u = au[AUXD ? r : 0][AUXD ? m : 0][AUXD ? q : 0];
+            const float g[4] = {zt_u2f(u.x << 16), zt_u2f(u.x & 0xFFFF0000u), zt_u2f(u.y << 16), zt_u2f(u.y & 0xFFFF0000u)};
+            const float neg = a.epi == 1 ? 0.2f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = a.epi == 3 ? v[j] + g[j] : v[j] * (g[j] > 0.f ? 1.f : neg);
+          }
           uint2 pk;
           pk.x = zt_f2bf2(v[0], v[1]);
           pk.y = zt_f2bf2(v[2], v[3]);
@@ -1288,15 +1313,17 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
     __syncthreads();
   }
   if (n_my > 0) {
-    if (EPI) glds_aux(n_my - 1, n_my & 1);
+    if (AUXL) glds_aux(n_my - 1, n_my & 1);
     store_tile(n_my - 1);
   }
 }
 
 int launch_conv_rs(ConvArgsH& a, hipStream_t stream) {
-  // forward layers (no fused aux operand): two 4-wave workgroups per CU on 4-row tiles; EPI layers: one 8-wave workgroup
+  // two 4-wave workgroups per CU on 4-row tiles (ZT_CONV_RS4=0: the one-workgroup 8-row form)
   static const int rt4 = getenv("ZT_CONV_RS4") ? atoi(getenv("ZT_CONV_RS4")) : 1;
-  const int rt = (!a.epi && rt4) ? 4 : 8;
+  // 64-cout layers with a fused aux operand stay on the 8-row form: at 144 VGPRs of weights the accumulator-layout aux read
+  // spills (measured +8 %); the 48-cout ones gain 14 % on the 4-row form
+  const int rt = (rt4 && !(a.epi && a.Cout == 64)) ? 4 : 8;
   a.tilesX = zt_cdiv(a.Wo, TW);
   a.tilesY = zt_cdiv(a.Ho, rt);
   const int ntiles = a.tilesX * a.tilesY;
@@ -1305,7 +1332,13 @@ int launch_conv_rs(ConvArgsH& a, hipStream_t stream) {
   const int kc = a.Cin <= 16 ? 0 : (a.Cin > 48 ? 2 : 1);       // 0: one K=16 chunk, 1: 32 + 16, 2: 32 + 32
 #define ZT_RS(nq, nm, cs, c32, c16)                                                                                            \
   {                                                                                                                            \
-    if (a.epi) hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, true, 8>), grid, block, 0, stream, a, ntiles);     \
+    if constexpr (!(cs)) {                                                                                                     \
+      if (a.epi && rt == 4) {                                                                                                  \
+        hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, true, 4>), grid, block, 0, stream, a, ntiles);            \
+        return 0;                                                                                                              \
+      }                                                                                                                        \
+    }                                                                                                                          \
+    if (a.epi) hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, true, 8>), grid, block, 0, stream, a, ntiles); \
     else if (rt == 4) hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, false, 4>), grid, block, 0, stream, a, ntiles); \
     else hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, false, 8>), grid, block, 0, stream, a, ntiles);          \
     return 0;                                                                                                                  \
