@@ -950,7 +950,9 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
   constexpr int RTH = RT, NTHR = 64 * RT, NST = RT == 8 ? 2 : 1;
   // fused aux operand (activation mask / residual): the 8-row form DMAs its tile into the idle staging buffer (AUXL); the 4-row
   // form has no second staging buffer and reads it in accumulator layout (8 bytes per lane and 16x16 block) half a loop ahead
-  constexpr bool AUXL = EPI && RT == 8, AUXD = EPI && RT == 4;
+  // (AUXD: 48 couts); with 64 couts (144 VGPRs of weights) that spills, so there the aux chunk is fetched by the store phase at
+  // the start of the next tile, where no accumulator is live (AUXS; the other workgroup of the CU covers the exposed latency)
+  constexpr bool AUXL = EPI && RT == 8, AUXD = EPI && RT == 4 && !COSPLIT, AUXS = EPI && RT == 4 && COSPLIT;
   constexpr int IR = RTH + 2, IC = TW + 2;
   constexpr int KC = C32 * 32 + C16 * 16;                       // input channels staged per pixel
   constexpr int PE = KC > 32 ? 64 : (KC > 16 ? 32 : 16);        // LDS elements per pixel; only the 128-byte rows need the swizzle
@@ -1145,7 +1147,17 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
       if (halo_in_flight) zt_wait_vmcnt<GLDS ? NGL : NPF>();
       else zt_wait_vmcnt0();
     }
-    uint4 v[NOUT];
+    uint4 v[NOUT], ux[AUXS ? NOUT : 1];
+    if constexpr (AUXS) {                                       // aux chunks straight from global (16 bytes per lane), all in flight
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) {
+        const int e = tid + i * NTHR, pl = e / CH8, ch = e % CH8;
+        int oy = oy0 + pl / TW, ox = ox0 + pl % TW;
+        oy = oy >= a.Ho ? a.Ho - 1 : oy;
+        ox = ox >= a.Wo ? a.Wo - 1 : ox;
+        ux[AUXS ? i : 0] = *reinterpret_cast<const uint4*>(a.aux + (unsigned)((oy * a.Wo + ox) * a.ldaux + ch * 8));
+      }
+    }
     if (!AUXL) {                                                // AUXL runs mid-loop with every accumulator live: one chunk at a time
 #pragma unroll
       for (int i = 0; i < NOUT; ++i) {
@@ -1158,9 +1170,15 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
       const int e = tid + i * NTHR, pl = e / CH8, ch = e % CH8;
       const int oy = oy0 + pl / TW, ox = ox0 + pl % TW;
       uint4 o;
-      if (AUXL) {
-        o = *reinterpret_cast<const uint4*>(sb + pl * CW + ((SWZO ? (ch ^ (pl & 7)) : ch) * 8));
-        const uint4 u = *reinterpret_cast<const uint4*>(ab + e * 8);
+      if (AUXL || AUXS) {
+        uint4 u;
+        if constexpr (AUXL) {
+          o = *reinterpret_cast<const uint4*>(sb + pl * CW + ((SWZO ? (ch ^ (pl & 7)) : ch) * 8));
+          u = *reinterpret_cast<const uint4*>(ab + e * 8);
+        } else {
+          o = v[i];
+          u = ux[AUXS ? i : 0];
+        }
         const unsigned vv[4] = {o.x, o.y, o.z, o.w}, uu[4] = {u.x, u.y, u.z, u.w};
         unsigned oo[4];
 #pragma unroll
@@ -1172,7 +1190,7 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
           oo[j] = zt_f2bf2(f0, f1);
         }
         o = make_uint4(oo[0], oo[1], oo[2], oo[3]);
-        __builtin_amdgcn_sched_barrier(0);                      // keep the chunks sequential (register pressure)
+        if constexpr (AUXL) __builtin_amdgcn_sched_barrier(0);  // keep the chunks sequential (register pressure)
       } else {
         o = v[i];
       }
@@ -1321,9 +1339,7 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
 int launch_conv_rs(ConvArgsH& a, hipStream_t stream) {
   // two 4-wave workgroups per CU on 4-row tiles (ZT_CONV_RS4=0: the one-workgroup 8-row form)
   static const int rt4 = getenv("ZT_CONV_RS4") ? atoi(getenv("ZT_CONV_RS4")) : 1;
-  // 64-cout layers with a fused aux operand stay on the 8-row form: at 144 VGPRs of weights the accumulator-layout aux read
-  // spills (measured +8 %); the 48-cout ones gain 14 % on the 4-row form
-  const int rt = (rt4 && !(a.epi && a.Cout == 64)) ? 4 : 8;
+  const int rt = rt4 ? 4 : 8;
   a.tilesX = zt_cdiv(a.Wo, TW);
   a.tilesY = zt_cdiv(a.Ho, rt);
   const int ntiles = a.tilesX * a.tilesY;
@@ -1332,11 +1348,9 @@ int launch_conv_rs(ConvArgsH& a, hipStream_t stream) {
   const int kc = a.Cin <= 16 ? 0 : (a.Cin > 48 ? 2 : 1);       // 0: one K=16 chunk, 1: 32 + 16, 2: 32 + 32
 #define ZT_RS(nq, nm, cs, c32, c16)                                                                                            \
   {                                                                                                                            \
-    if constexpr (!(cs)) {                                                                                                     \
-      if (a.epi && rt == 4) {                                                                                                  \
-        hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, true, 4>), grid, block, 0, stream, a, ntiles);            \
-        return 0;                                                                                                              \
-      }                                                                                                                        \
+    if (a.epi && rt == 4) {                                                                                                    \
+      hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, true, 4>), grid, block, 0, stream, a, ntiles);              \
+      return 0;                                                                                                                \
     }                                                                                                                          \
     if (a.epi) hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, true, 8>), grid, block, 0, stream, a, ntiles); \
     else if (rt == 4) hipLaunchKernelGGL((conv_rs_bf16_kernel<nq, nm, cs, c32, c16, false, 4>), grid, block, 0, stream, a, ntiles); \
