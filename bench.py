@@ -173,7 +173,7 @@ def main():
             alg = (3 * (2 * px * 64 * 2) + 3 * (3 * px * 64 * 2)) / 6.0
             traffic = None
             try:        # measured HBM traffic of the same kernel from the committed PMC passes (profiles/, see its _how)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_k_pmc_summary.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_l_pmc_summary.json")))
                 if (H, W) == (1080, 1920):
                     traffic = pm["kernels"]["conv_rs_bf16_kernel<2, 2, true, 2, 0>"]["hbm_bytes_per_launch_avg"]
             except Exception:
