@@ -4,41 +4,47 @@
 One "step" = one steady-state frame of the reference loop (train.py:119-131): forward incl. bilinear downscale +
 histogram equalisation + RAFT(12 iterations) + fused backward warp, LossFunction, hand-written backward, one
 flat-bucket gradient all-reduce over RCCL (N > 1), clip_grad_norm_(5) + Adam.  Frames are synthetic
-(zero-tig_amd/synth.py) and already resident in HBM when the timed region starts.
+(zero-tig_amd/synth.py) and already resident in HBM when the timed region starts (`value`); the same K steps are timed
+a second time with the reference's per-step host->device copy of the frame (train.py:125) inside the step (`with_h2d`).
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel, measured live with HIP
-events on the launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N == 1 only).
+Launch: `python bench.py --gpus N ...` starts N ranks itself (one process per GPU, RCCL) when it is not already running
+under torch.distributed.run / torchrun (WORLD_SIZE unset); under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel), `roofline_extra` (the warp and
+the correlation volume, BASELINE.json's HBM targets) -- all timed live with HIP events on the launch stream in a separate
+pass after the timed region -- and `cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N == 1 only).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--of_scale", type=int, default=3)
     ap.add_argument("--dataset", type=str, default="RLV")
-    ap.add_argument("--cpu-baseline", type=str, default="540p", choices=["540p", "1080p", "none"])
+    ap.add_argument("--cpu-baseline", type=str, default="1080p", choices=["540p", "1080p", "none"])
     ap.add_argument("--frames", type=int, default=6, help="distinct synthetic frames kept in HBM (cycled)")
     ap.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"],
                     help="bf16: activations+weights bf16 in HBM, fp32 accumulate (BASELINE config 3); fp32: exact-fp32 parity mode")
+    ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a captured hipGraph (default); 0: eager launches")
     return ap.parse_args()
 
 
@@ -62,44 +68,88 @@ def host_cores():
     return max(1, min(n, 32))
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one process per GPU) BEFORE this process touches the GPU
+    and pass rank 0's JSON line through.  Children see WORLD_SIZE and therefore never recurse."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = None if r == 0 else subprocess.DEVNULL          # rank 0 prints the line on our stdout; stderr is shared
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                r = p.poll()
+                if r is None:
+                    continue
+                procs.remove(p)
+                if r != 0:                                   # one rank died: the others would wait in a collective forever
+                    rc = r
+                    for q in procs:
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
 def cpu_baseline(kind, of_scale, dataset):
-    """The oracle (a torch-CPU restatement of the reference, pinned to reference-generated goldens) timed on the host cores.
-    Sample: one steady-state training step (frame 1 of a clip; frame 0 primes the recurrent cache, untimed)."""
+    """the oracle (a torch-CPU restatement of the reference, pinned to reference-generated goldens) timed on the host
+    cores on the same synthetic clip: 1 cache-priming new-sequence step, 1 warm-up + 3 timed steady-state steps, median."""
+    import torch
     from oracle import zt_oracle
     synth = importlib.import_module("zero-tig_amd.synth")
     H, W = (540, 960) if kind == "540p" else (1080, 1920)
     cores = host_cores()
     torch.set_num_threads(cores)
-    log("cpu_baseline: oracle on %d host threads at %dx%d (cache-priming step)" % (cores, H, W))
     tr = zt_oracle.OracleTrainer(zt_oracle.to_torch_state(synth.make_state(1)), is_WB=(dataset == "underwater"), of_scale=of_scale)
-    x0 = torch.from_numpy(synth.lowlight_frame(0, H, W))
-    x1 = torch.from_numpy(synth.lowlight_frame(1, H, W))
-    tr.step(x0, True)
-    log("cpu_baseline: timed steady-state step")
-    t0 = time.perf_counter()
-    tr.step(x1, False)
-    dt = time.perf_counter() - t0
+    times = []
+    for t in range(5):
+        x = torch.from_numpy(synth.lowlight_frame(t, H, W))
+        log("cpu_baseline: oracle step %d/5 on %d host threads at %dx%d (%s)" %
+            (t + 1, cores, H, W, "new sequence, primes the cache" if t == 0 else ("warm-up" if t == 1 else "timed")))
+        t0 = time.perf_counter()
+        tr.step(x, t == 0)
+        dt = time.perf_counter() - t0
+        if t >= 2:
+            times.append(dt)
+    med = sorted(times)[1]
     scale = (H * W) / (1080.0 * 1920.0)
-    return {"value": (1.0 / dt) * scale, "unit": "frames/s (1080p-equivalent)", "cores": cores, "kind": "port",
-            "sample": "1 steady-state training step (fwd+RAFT+warp+loss+bwd+clip+Adam, fp32) of the CPU oracle at %dx%d in %.2f s, "
-                      "after 1 untimed cache-priming step; scaled by pixel count to 1080p" % (H, W, dt),
-            "seconds_per_step_sample": dt}
+    return {"value": (1.0 / med) * scale, "unit": "frames/s" if scale == 1.0 else "frames/s (1080p-equivalent)", "cores": cores,
+            "kind": "port",
+            "sample": "median of 3 steady-state training steps (fwd+RAFT+warp+loss+bwd+clip+Adam, fp32) of the CPU oracle at %dx%d "
+                      "(%.2f / %.2f / %.2f s) after 1 cache-priming + 1 warm-up step%s"
+                      % (H, W, times[0], times[1], times[2], "" if scale == 1.0 else "; scaled by pixel count to 1080p"),
+            "seconds_per_step_median": med}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
+    if os.environ.get("ZT_BENCH_LAUNCH_PROBE"):       # tests/test_dropin.py: what a rank sees, without touching the GPU
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}), flush=True)
+        return
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     synth = importlib.import_module("zero-tig_amd.synth")
     net_mod = importlib.import_module("zero-tig_amd.network")
@@ -115,19 +165,19 @@ def main():
     H, W = a.height, a.width
     nfr = max(2, min(a.frames, a.steps + a.warmup + 1))
     # each rank owns its own clip (seed 2 + 1000*rank): frame-level data parallelism with per-rank recurrent cache
-    frames = []
+    host_frames, frames = [], []
     for t in range(nfr):
-        frames.append(torch.from_numpy(synth.lowlight_frame(t, H, W, seed=2 + 1000 * rank)).to(dev))
+        hf = torch.from_numpy(synth.lowlight_frame(t, H, W, seed=2 + 1000 * rank)).pin_memory()
+        host_frames.append(hf)
+        frames.append(hf.to(dev))
         if rank == 0:
             log("synthetic frame %d/%d resident in HBM" % (t + 1, nfr))
 
-    def step(i):
-        net.is_new_seq = (i == 0)
-        opt.zero_grad()
-        loss = net._loss(frames[i % nfr])
-        loss.backward()
-        opt.step()
-        return loss
+    stepper = optim.TrainStep(net, opt, use_graph=bool(a.graph))
+
+    def step(i, from_host=False):
+        src = host_frames if from_host else frames
+        return stepper(src[i % nfr], is_new_seq=(i == 0))
 
     def sync():
         if world > 1:
@@ -136,73 +186,113 @@ def main():
 
     it = 0
     if rank == 0:
-        log("warm-up")
-    for _ in range(max(1, a.warmup)):           # at least one step: frame 0 primes the cache (new sequence, no RAFT)
+        log("warm-up (%s)" % ("hipGraph capture + replay" if a.graph else "eager launches"))
+    for _ in range(max(2, a.warmup)):     # >= 2 steps: frame 0 primes the cache (new sequence, no RAFT), frame 1 is the first steady-state step
         step(it)
         it += 1
-    # live roofline instrumentation of the dominant kernel (Enhancer 64->64 3x3 conv: fwd + dgrad launches)
-    prof = {"match": (3, 3, 1, 64, 64, H, W), "events": []}
-    net._ops.profile = prof
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step(it)
-        it += 1
-    sync()
-    dt = time.perf_counter() - t0
-    net._ops.profile = None
-    last_loss = float(loss.detach())
+
+    def timed(from_host):
+        nonlocal it
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        sync()
+        t0 = time.perf_counter()
+        ev[0].record()
+        for k in range(a.steps):
+            loss = step(it, from_host)
+            ev[k + 1].record()
+            it += 1
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax)
+        per = sorted(ev[k].elapsed_time(ev[k + 1]) for k in range(a.steps))
+        return dt, per[len(per) // 2], float(loss.detach())
+
+    dt, med_ms, last_loss = timed(False)
     if rank == 0:
-        log("timed region done: %.2f ms/step" % (1e3 * dt / a.steps))
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+        log("timed region done: %.2f ms/step (median of the per-step HIP-event times %.2f ms)" % (1e3 * dt / a.steps, med_ms))
+    dt_h, med_h, _ = timed(True)
+    if rank == 0:
+        log("with the per-step H2D copy of the frame: %.2f ms/step" % (1e3 * dt_h / a.steps))
     value = world * a.steps / dt
 
-    roof = None
-    if prof["events"]:
-        ms = [s.elapsed_time(e) for s, e in prof["events"]]
-        avg_ms = sum(ms) / len(ms)
-        flops = 2.0 * 9 * 64 * 64 * H * W
-        tf = flops / (avg_ms * 1e-3) / 1e12
+    # ---- live roofline instrumentation, separate untimed pass (eager launches, HIP events around the matched kernels)
+    px = float(H) * W
+    h8, w8 = ((H // a.of_scale + 7) // 8), ((W // a.of_scale + 7) // 8)
+    npx = h8 * w8
+    prof = {"match": {(3, 3, 1, 64, 64, H, W): "conv64", (1, 1, 1, 256, npx, h8, w8): "corr"}, "events": {}}
+    net._ops.profile = prof
+    eager = optim.TrainStep(net, opt, use_graph=False)
+    for _ in range(3):
+        eager(frames[it % nfr], is_new_seq=False)
+        it += 1
+    torch.cuda.synchronize()
+    net._ops.profile = None
+
+    def avg_ms(name):
+        ev = prof["events"].get(name, [])
+        return (sum(s.elapsed_time(e) for s, e in ev) / len(ev), len(ev)) if ev else (None, 0)
+
+    roof, extra = None, {}
+    ms, nl = avg_ms("conv64")
+    if ms is not None:
+        flops = 2.0 * 9 * 64 * 64 * px
+        tf = flops / (ms * 1e-3) / 1e12
         if a.precision == "bf16":
             # bf16: 288 FLOP/B sits at the ridge (2500 TF / 8 TB/s = 312); priced against HBM.  Per launch the kernel reads the
             # 64-ch bf16 input once and writes the 64-ch output once (the three dgrad launches also read the residual df).
-            px = float(H) * W
             alg = (3 * (2 * px * 64 * 2) + 3 * (3 * px * 64 * 2)) / 6.0
-            traffic = None
-            try:        # measured HBM traffic of the same kernel from the committed PMC passes (profiles/, see its _how)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_l_pmc_summary.json")))
-                if (H, W) == (1080, 1920):
-                    traffic = pm["kernels"]["conv_rs_bf16_kernel<2, 2, true, 2, 0>"]["hbm_bytes_per_launch_avg"]
-            except Exception:
-                pass
-            gbs = alg / (avg_ms * 1e-3) / 1e9
+            gbs = alg / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "conv_rs_bf16_kernel<2,2,true,2,0,*> (Enhancer 64->64 3x3: 3 fwd + 3 dgrad launches per step)",
-                    "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic, "launches": len(ms),
-                    "avg_ms": avg_ms, "algorithmic_bytes_per_launch": alg,
+                    "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                    "launches": nl, "avg_ms": ms, "algorithmic_bytes_per_launch": alg,
                     "mfma_view": {"achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_BF16_MFMA_TFLOPS, "frac": tf / PEAK_BF16_MFMA_TFLOPS,
                                   "algorithmic_flops_per_launch": flops}}
+            try:        # NOT measured in this run: HBM traffic of the same kernel from the committed PMC passes (profiles/)
+                src = "profiles/r02_pmc_summary.json"
+                pm = json.load(open(os.path.join(ROOT, src)))
+                if (H, W) == (1080, 1920):
+                    roof["traffic_from_profile"] = {"bytes_per_launch": pm["kernels"]["conv_rs_bf16_kernel<2, 2, true, 2, 0>"]["hbm_bytes_per_launch_avg"],
+                                                    "source": src}
+            except Exception:
+                pass
         else:
             roof = {"bound": "mfma", "kernel": "conv_mfma_f32_kernel<3,3,1,4> (Enhancer 64->64 3x3, fwd+dgrad)", "achieved": tf,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                    "launches": len(ms), "avg_ms": avg_ms, "algorithmic_flops_per_launch": flops}
+                    "launches": nl, "avg_ms": ms, "algorithmic_flops_per_launch": flops}
+    ms, nl = avg_ms("warp2")
+    if ms is not None:          # utils.py:203-230 x2 fused: read 2 images + flow, write 2 images (fp32 planar)
+        alg = 4 * px * 3 * 4 + (H // a.of_scale) * (W // a.of_scale) * 2 * 4.0
+        extra["warp2_kernel"] = {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_ms": ms, "launches": nl,
+                                 "algorithmic_bytes_per_launch": alg}
+    ms, nl = avg_ms("corr")
+    if ms is not None:          # corr.py:52-60: the fp32 all-pairs volume written once (+ both feature maps read)
+        alg = float(npx) * npx * 4 + 2 * npx * 256 * (2 if a.precision == "bf16" else 4)
+        extra["corr_volume"] = {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_ms": ms, "launches": nl,
+                                "algorithmic_bytes_per_launch": alg}
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_baseline != "none":
         cpu = cpu_baseline(a.cpu_baseline, a.of_scale, a.dataset)
 
     if rank == 0:
-        out = {"metric": "1080p self-supervised training frames/sec", "value": value, "unit": "frames/s", "n_gpus": world,
-               "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": ("bf16" if a.precision == "bf16" else "f32"), "data": "synthetic",
+        label = "1080p" if (H, W) == (1080, 1920) else "%dx%d" % (H, W)
+        out = {"metric": "%s self-supervised training frames/sec" % label, "value": value, "unit": "frames/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "ms_per_step_median": med_ms,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": ("bf16" if a.precision == "bf16" else "f32"), "data": "synthetic",
                "config": {"workload": "%dx%d BVI-RLV-style self-supervised training step (enhance+RAFT flow+warp+loss+backward+clip+Adam), "
                                       "batch 1 frame per GPU, of_scale=%d, dataset=%s" % (H, W, a.of_scale, a.dataset),
                           "parallelism": "dp%d (one contiguous clip per rank, one 370 KB flat-bucket all-reduce per step)" % world,
-                          "global_batch": world},
-               "roofline": roof, "cpu_baseline": cpu, "final_loss": last_loss}
-        print(json.dumps(out))
+                          "global_batch": world, "launch": "hipGraph replay" if a.graph else "eager"},
+               "with_h2d": {"value": world * a.steps / dt_h, "ms_per_step": 1e3 * dt_h / a.steps, "ms_per_step_median": med_h,
+                            "note": "same K steps with the frame's 24.9 MB (1080p) pinned-host -> HBM copy inside every step (train.py:125)"},
+               "roofline": roof, "roofline_extra": extra, "cpu_baseline": cpu, "final_loss": last_loss}
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -179,6 +179,11 @@ int zt_clip_adam_f32(float* p, const float* g, float* m, float* v, long long n, 
                      float* gnorm_out, zt_stream_t stream);
 
 
+/* y[i] += alpha[0] * x[i]: `loss.backward()` (train.py:129) hands the step's parameter gradients (already computed next to the
+ * loss by the fused plan) to the optimizer's flat bucket, scaled by the upstream gradient that autograd holds on the device. */
+int zt_axpy_dev_f32(float* y, const float* x, const float* alpha, long long n, zt_stream_t stream);
+
+
 /* ---- hardware self-test probes (zt_probe.hip): pin the test emulator's model of gfx950 instructions to the chip ----- */
 /* ds_read_b64_tr_b16 on a [16][64] image of 16-bit codes: out[lane*4+q]; bf16 MFMA 16x16x32: D[16][16] = A[16][32] B[32][16] */
 int zt_probe_tr16(const unsigned short* img, unsigned short* out, int col0, zt_stream_t stream);

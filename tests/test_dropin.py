@@ -139,3 +139,20 @@ def test_dropin_loss_and_utils(backend, oracle, synth):
     g6 = load_golden("g6_ops")
     look = cb(torch.from_numpy(g6["lookup_coords"]).to(dev))
     assert float((look.cpu() - torch.from_numpy(g6["lookup_out"])).abs().max()) < 2e-5
+
+
+def test_bench_gpus_flag_launches_one_rank_per_gpu():
+    """`python bench.py --gpus N` outside a launcher starts N ranks itself (the flag used to be ignored); under a launcher
+    (WORLD_SIZE set) it must not fork again.  Probe mode: ranks report their environment instead of touching the GPU."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ZT_BENCH_LAUNCH_PROBE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["RANK"] == "0" and lines[0]["WORLD_SIZE"] == "4" and lines[0]["MASTER_ADDR"] == "127.0.0.1"
+    env.update(RANK="1", LOCAL_RANK="1", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout.strip())["RANK"] == "1"

@@ -252,3 +252,75 @@ def test_eval_mode_bn_training_quirk(backend, synth, oracle):
             assert rel_l2(p.grad, tr.W[n].grad) < 2e-3, (n, rel_l2(p.grad, tr.W[n].grad))
     assert int(net.enhance.conv[1].num_batches_tracked) == 0
     assert float((net.enhance.conv[1].running_mean.cpu() - torch.from_numpy(st["enhance.conv.1.running_mean"])).abs().max()) == 0.0
+
+
+def test_clipadam_rebinds_stray_grads(backend, synth):
+    """`model.zero_grad()` (set_to_none) detaches p.grad from the flat bucket; step() must pick the stray gradients up
+    (same update as with optimizer.zero_grad()) instead of silently applying zeros, and refuse parameters that moved."""
+    ops, dev, bname = backend
+    optim = importlib.import_module("zero-tig_amd.optim")
+    x = frames(synth, 1, 48, 64)[0].to(dev)
+    flats = []
+    for mode in ("opt", "model"):
+        net = _network(ops, dev, synth, 1, of_scale=3).train()
+        opt = optim.ClipAdam(net)
+        (opt if mode == "opt" else net).zero_grad()
+        net.is_new_seq = True
+        net._loss(x).backward()
+        gn = float(opt.step())
+        assert gn > 0
+        flats.append(opt.fp.flat.clone())
+        assert all(p.grad.data_ptr() == opt.fp.grad.data_ptr() + 4 * o for p, o in zip(opt.fp.params, opt.fp.offsets))
+    assert torch.equal(flats[0], flats[1])
+    for p in opt.fp.params[:1]:
+        p.data = p.data.clone()
+    with pytest.raises(RuntimeError):
+        opt.step()
+
+
+def test_trainstep_eager_equals_manual_loop(backend, synth):
+    """optim.TrainStep (gradients written straight into the flat bucket, no autograd) == zero_grad / _loss / backward / step."""
+    ops, dev, bname = backend
+    optim = importlib.import_module("zero-tig_amd.optim")
+    xs = [f.to(dev) for f in frames(synth, 2, 48, 64)]
+    out = []
+    for mode in ("manual", "trainstep"):
+        net = _network(ops, dev, synth, 1, of_scale=3).train()
+        opt = optim.ClipAdam(net)
+        ts = optim.TrainStep(net, opt, use_graph=False)
+        ls = []
+        for x in xs:                                   # two new-sequence frames (RAFT through the emulator takes minutes)
+            if mode == "manual":
+                net.is_new_seq = True
+                opt.zero_grad()
+                loss = net._loss(x)
+                loss.backward()
+                opt.step()
+            else:
+                loss = ts(x, is_new_seq=True)
+            ls.append(float(loss.detach()))
+        out.append((ls, opt.fp.flat.clone()))
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
+
+
+@pytest.mark.gpu
+def test_trainstep_hipgraph_replay_equals_eager(hip_ops, synth):
+    """The captured hipGraph of the steady-state step replays to the same bits as eager launches: losses of every frame, final
+    weights, Adam moments, BN running statistics and the recurrent cache (6 frames: 1 new-sequence, 1 eager steady-state,
+    capture, 3 replays)."""
+    ops, dev = hip_ops
+    optim = importlib.import_module("zero-tig_amd.optim")
+    H, W = 128, 160
+    host = frames(synth, 6, H, W)
+    res = []
+    for use_graph in (False, True):
+        net = _network(ops, dev, synth, 1, of_scale=1).train()
+        opt = optim.ClipAdam(net)
+        ts = optim.TrainStep(net, opt, use_graph=use_graph)
+        ls = [float(ts(x.pin_memory() if use_graph else x.to(dev), is_new_seq=(t == 0)).detach()) for t, x in enumerate(host)]
+        assert (ts.graph is not None) == use_graph
+        bn = net.enhance.conv[1]
+        res.append((ls, opt.fp.flat.clone(), opt.m.clone(), bn.running_mean.clone(), int(bn.num_batches_tracked), net.last_H3.clone()))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert (a == b) if isinstance(a, int) else torch.equal(a, b)

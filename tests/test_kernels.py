@@ -305,32 +305,47 @@ def test_raft_ops_golden(backend, oracle, synth):
 
 
 def test_raft_update_step_golden(backend, oracle, synth):
+    """One BasicUpdateBlock step (update.py:114-136) through the plan's HIP kernels -- fused 4-level lookup, motion encoder,
+    SepConvGRU x2, flow head, mask head, convex up-sampling -- against the reference's own `ub_net` / `ub_dflow` / `ub_mask` /
+    `ub_up` (golden g6: `net.raft.update_block(h, inp, corr, flow)` and `upsample_flow`)."""
     import importlib
     ops, dev, _ = backend
+    CV = importlib.import_module("zero-tig_amd.ops").CV
     g = load_golden("g6_ops")
     raft_mod = importlib.import_module("zero-tig_amd.raft")
     st = synth.make_state(3)
     W = {k: torch.from_numpy(np.array(v)).to(dev) for k, v in st.items() if k.startswith("raft.")}
     plan = raft_mod.RaftPlan(ops, W, dev)
-    # drive one refinement step through the plan's building blocks by running `run` internals on prepared state is
-    # covered end-to-end in test_engine (sequence goldens); here: convex upsample against the golden directly.
     h, w = 16, 24
-    fl = torch.from_numpy(g["lookup_coords"]) - torch.stack(torch.meshgrid(torch.arange(w), torch.arange(h), indexing="xy"), 0).float()[None]
-    dfl = torch.from_numpy(g["ub_dflow"])
-    # recompute the full mask with the oracle (the golden stores every 9th channel) and check it against the golden slice
     hh = torch.tanh(torch.from_numpy(synth.normal("ops.h", (1, 128, h, w), 0.0, 1.0, 7)))
     inp = torch.relu(torch.from_numpy(synth.normal("ops.inp", (1, 128, h, w), 0.0, 1.0, 7)))
     f1 = torch.from_numpy(synth.normal("ops.f1", (1, 256, h, w), 0.0, 1.0, 7))
     f2 = torch.from_numpy(synth.normal("ops.f2", (1, 256, h, w), 0.0, 1.0, 7))
+    coords = torch.from_numpy(g["lookup_coords"])
+    HX = torch.zeros(1, h, w, 384)
+    HX[..., :128], HX[..., 128:256] = _nhwc(hh), _nhwc(inp)
+    state = plan.new_state(h, w, HX.to(dev), coords=coords[0].permute(1, 2, 0).reshape(-1, 2).contiguous())
+    state.corr0 = ops.conv2d(CV(_nhwc(f1).to(dev)), f2.view(1, 256, h * w).to(dev).contiguous(), None, h * w, 1, 1, alpha=1.0 / 16.0)
+    state.levels = ops.corr_pyramid(state.corr0, h, w)
+    plan.refine_step(state)
+    net_out = state.HX.cpu()[..., :128].permute(0, 3, 1, 2)
+    assert maxerr(net_out, torch.from_numpy(g["ub_net"])) < 5e-5, maxerr(net_out, torch.from_numpy(g["ub_net"]))
+    dfl = state.delta.cpu()[..., :2].permute(0, 3, 1, 2)
+    assert maxerr(dfl, torch.from_numpy(g["ub_dflow"])) < 1e-4, maxerr(dfl, torch.from_numpy(g["ub_dflow"]))
+    _, flow_up, mask = plan.finish(state, 8 * h, 8 * w)
+    assert maxerr(mask.cpu().permute(0, 3, 1, 2)[:, ::9], torch.from_numpy(g["ub_mask"])) < 1e-4
+    assert maxerr(flow_up, torch.from_numpy(g["ub_up"])) < 2e-4, maxerr(flow_up, torch.from_numpy(g["ub_up"]))
+    # and the up-sampler alone on the ORACLE's mask / flow (isolates raft.py:64-75)
+    fl = coords - torch.stack(torch.meshgrid(torch.arange(w), torch.arange(h), indexing="xy"), 0).float()[None]
     pyr = oracle.corr_pyramid(f1, f2)
     Wt = oracle.to_torch_state(st)
     with torch.no_grad():
-        _, mask, dfl_o = oracle.update_block(Wt, "raft.update_block", hh, inp, oracle.corr_lookup(pyr, torch.from_numpy(g["lookup_coords"])), fl)
-    assert maxerr(mask[:, ::9], torch.from_numpy(g["ub_mask"])) < 1e-4
+        _, mask_o, dfl_o = oracle.update_block(Wt, "raft.update_block", hh, inp, oracle.corr_lookup(pyr, coords), fl)
+    assert maxerr(mask_o[:, ::9], torch.from_numpy(g["ub_mask"])) < 1e-4
     f4 = torch.zeros(1, h, w, 4)
     f4[..., :2] = (fl + dfl_o)[0].permute(1, 2, 0)
     up = torch.empty(1, 2, 8 * h, 8 * w, device=dev)
-    ops.lib.call("zt_convex_upsample_f32", f4.to(dev), 4, _nhwc(mask).to(dev), 576, up, None, h, w, None if dev.type == "cpu" else torch.cuda.current_stream().cuda_stream)
+    ops.lib.call("zt_convex_upsample_f32", f4.to(dev), 4, _nhwc(mask_o).to(dev), 576, up, None, h, w, None if dev.type == "cpu" else torch.cuda.current_stream().cuda_stream)
     assert maxerr(up, torch.from_numpy(g["ub_up"])) < 1e-4
 
 

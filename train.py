@@ -122,7 +122,9 @@ def main():
         logging.info("train-epoch %03d %f", epoch, np.average(losses))
         if rank == 0:
             utils.save(model, os.path.join(model_path, "weights_%d.pt" % epoch))
-            model.eval()
+        # every rank switches mode together: under DP the gradients that get all-reduced must come from the same BN mode
+        model.eval()
+        if rank == 0:
             with torch.no_grad():
                 for it, (inp, img_name, img_path, last_img_path) in enumerate(test_queue):
                     model.is_new_seq = it == 0 or utils.sequential_judgment(img_path[0], last_img_path[0])
@@ -133,9 +135,9 @@ def main():
                     os.makedirs(args.save + "/result/enhance/", exist_ok=True)
                     Image.fromarray(save_images(H3)).save(args.save + "/result/denoise/" + name + "_denoise_" + str(epoch) + ".png", "PNG")
                     Image.fromarray(save_images(H2)).save(args.save + "/result/enhance/" + name + "_enhance_" + str(epoch) + ".png", "PNG")
-            # NOTE: the reference stays in eval() from here on (train.py:138, SURVEY A-14); this loop returns to train mode.
-            if not args.reference_eval_quirk:
-                model.train()
+        # NOTE: the reference stays in eval() from here on (train.py:138, SURVEY A-14); this loop returns to train mode.
+        if not args.reference_eval_quirk:
+            model.train()
 
 
 if __name__ == "__main__":

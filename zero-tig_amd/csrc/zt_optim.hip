@@ -40,7 +40,21 @@ __global__ void __launch_bounds__(256) clip_adam_kernel(float* __restrict__ p, c
   p[i] = pi - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
 }
 
+// y += (*alpha) * x: hands the step's gradients to the optimizer's bucket (loss.backward() with an upstream gradient on device)
+__global__ void __launch_bounds__(256) axpy_dev_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ alpha,
+                                                       long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = fmaf(alpha[0], x[i], y[i]);
+}
+
 }  // namespace
+
+extern "C" int zt_axpy_dev_f32(float* y, const float* x, const float* alpha, long long n, hipStream_t stream) {
+  ZT_REQUIRE(y && x && alpha && n > 0);
+  hipLaunchKernelGGL(axpy_dev_kernel, dim3((unsigned)zt_cdivl(n, 256)), dim3(256), 0, stream, y, x, alpha, n);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
 
 extern "C" int zt_clip_adam_f32(float* p, const float* g, float* m, float* v, long long n, float* partial, int nblk, float gscale,
                                 float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,

@@ -159,11 +159,19 @@ class _StepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, inp, *params):
         loss, grads = net._loss_and_grads(inp)
-        ctx.grads = grads
+        ctx.grads, ctx.net = grads, net
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, gout):
+        net = ctx.net
+        fp, scratch = net.__dict__.get("_flat"), net.__dict__.get("_scratch")
+        if (fp is not None and scratch is not None and fp.intact() and ctx.grads and ctx.grads[0].data_ptr() == scratch.data_ptr()
+                and all(p.grad is not None and p.grad.data_ptr() == fp.grad.data_ptr() + 4 * o for p, o in zip(fp.params, fp.offsets))):
+            # p.grad are views of the optimizer's flat bucket: ONE launch accumulates all 20 gradients (bucket += gout * scratch)
+            from .lib import current_stream
+            net._ops.lib.call("zt_axpy_dev_f32", fp.grad, scratch, gout.detach().float().contiguous(), fp.n, current_stream(fp.grad.device))
+            return (None, None) + (None,) * len(ctx.grads)
         return (None, None) + tuple(g * gout for g in ctx.grads)
 
 
@@ -229,8 +237,27 @@ class _ZeroTIGBase(nn.Module):
         return fp
 
     def update_H3(self, H3, s3):                            # model.py:217-219
+        st = self.__dict__.get("_static_cache")
+        if st is not None and tuple(st[0].shape) == tuple(H3.shape):
+            # hipGraph mode (optim.TrainStep): the recurrent cache keeps its address from frame to frame
+            st[0].copy_(H3.detach())
+            st[1].copy_(s3.detach())
+            self.last_H3, self.last_s3 = st
+            return
         self.last_H3 = H3.detach()
         self.last_s3 = s3.detach()
+
+    def enable_static_cache(self, shape):
+        """Allocate fixed buffers for last_H3 / last_s3 ([1,3,H,W]); update_H3 then copies into them (hipGraph replay needs stable
+        addresses).  An existing cache is carried over."""
+        dev = self._trainable()[0][1].device
+        st = (torch.zeros((1, 3) + tuple(shape[-2:]), dtype=torch.float32, device=dev),
+              torch.zeros((1, 3) + tuple(shape[-2:]), dtype=torch.float32, device=dev))
+        if self.last_H3 is not None and tuple(self.last_H3.shape) == tuple(st[0].shape):
+            st[0].copy_(self.last_H3)
+            st[1].copy_(self.last_s3)
+            self.last_H3, self.last_s3 = st
+        self.__dict__["_static_cache"] = st
 
     def update_cache(self, last_H3, last_s3, L2):           # model.py:221-259
         _, rp = self._plan()
@@ -266,7 +293,10 @@ class Network(_ZeroTIGBase):
             self.last_H3_wp, self.last_s3_wp = eng.last_wp
         else:
             # the cache update needs L2 of the CURRENT frame (model.py:164), which the engine produces first
-            outs = eng.forward(x, keep=keep, cache_fn=lambda L2: rp.update_cache(self.last_H3, self.last_s3, L2, self.of_scale))
+            # `_teacher_flow` (parity tests only): warp with the oracle's flow instead of the plan's own RAFT result, which isolates
+            # everything downstream of RAFT at the new-sequence tolerance (tests/test_scale_gpu.py)
+            outs = eng.forward(x, keep=keep, cache_fn=lambda L2: rp.update_cache(
+                self.last_H3, self.last_s3, L2, self.of_scale, flow_up=self.__dict__.get("_teacher_flow")))
             self.last_H3_wp, self.last_s3_wp = eng.last_wp
         return outs
 
@@ -274,11 +304,17 @@ class Network(_ZeroTIGBase):
         """-> the reference's 23-tuple (model.py:203); values only (the training gradient path is `_loss`)."""
         return self._forward_impl(input, keep=False)
 
-    def _loss_and_grads(self, input):
+    def _loss_and_grads(self, input, into=None):
+        """-> (loss[1], [gradient tensors in _trainable() order]).  into: flat fp32 buffer (the optimizer's gradient bucket) that
+        is zeroed and receives the gradients directly; default: a scratch bucket / fresh tensors for autograd to hand over."""
         outs = self._forward_impl(input, keep=True)
         eng = self._eng
         fp = self.__dict__.get("_flat")
-        if fp is not None and fp.intact():
+        if into is not None:
+            assert fp is not None and fp.intact() and into.numel() == fp.n
+            into.zero_()
+            grads = fp.grad_views(into)
+        elif fp is not None and fp.intact():
             scratch = self.__dict__.get("_scratch")
             if scratch is None or scratch.numel() != fp.n or scratch.device != fp.flat.device:
                 scratch = torch.empty_like(fp.flat)

@@ -46,6 +46,23 @@ class Ops:
     def _s(self, t):
         return current_stream(t.device)
 
+    # live roofline measurement (bench.py): `self.profile = {"match": {conv geometry tuple: name}, "events": {name: [(e0, e1)]}}`
+    # brackets the matching launches with HIP events on the launch stream (torch's current stream IS the launch stream here)
+    profile = None
+
+    def _ev_begin(self, name):
+        if self.profile is None or name is None:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (name, e0)
+
+    def _ev_end(self, tok):
+        if tok is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.profile["events"].setdefault(tok[0], []).append((tok[1], e1))
+
     # ---- utils/utils.py:203-230 warp_tensor (x2 fused) ---------------------------------------------------
     def warp2(self, flow, imgA, imgB=None, want_taps=False):
         """flow [1,2,Hf,Wf], imgA/imgB [1,C,H,W] -> warped A, warped B (and int32 taps [H,W,2])."""
@@ -55,7 +72,9 @@ class Ops:
         outA = torch.empty_like(imgA)
         outB = torch.empty_like(imgB) if imgB is not None else None
         taps = torch.empty((H, W, 2), dtype=torch.int32, device=imgA.device) if want_taps else None
+        tok = self._ev_begin("warp2")
         self.lib.call("zt_warp2_f32", flow, Hf, Wf, imgA, imgB, outA, outB, taps, C, H, W, self._s(imgA))
+        self._ev_end(tok)
         return (outA, outB, taps) if want_taps else (outA, outB)
 
     # ---- stencils -------------------------------------------------------------------------------------------
@@ -186,17 +205,11 @@ class Ops:
         if epi:
             av = _cv(aux)
             auxp, ldaux = av.ptr, av.ld
-        prof = getattr(self, "profile", None)
-        timed = prof is not None and prof["match"] == (KH, KW, stride, Cin, Cout, x.H, x.W)
-        if timed:       # live roofline measurement (bench.py): HIP events on the launch stream around this kernel
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        tok = self._ev_begin(self.profile["match"].get((KH, KW, stride, Cin, Cout, x.H, x.W))) if self.profile else None
         self.lib.call("zt_conv2d_nhwc_f32", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin, wdev.data_ptr() + 4 * w_coff, ldw, bias, yptr, ldy,
                       int(out_planar), Cout, KH, KW, stride, pad[0], pad[1], ACT[act], float(alpha), auxp, ldaux, epi,
                       self._s(x.t))
-        if timed:
-            e1.record()
-            prof["events"].append((e0, e1))
+        self._ev_end(tok)
         return out
 
     def slab(self, dev, nbytes=96 << 20):
@@ -364,17 +377,11 @@ class Ops:
             av = _cv(aux)
             assert av.t.dtype == torch.bfloat16
             auxp, ldaux = av.ptr, av.ld
-        prof = getattr(self, "profile", None)
-        timed = prof is not None and prof["match"] == (KH, KW, stride, Cin, Cout, x.H, x.W)
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        tok = self._ev_begin(self.profile["match"].get((KH, KW, stride, Cin, Cout, x.H, x.W))) if self.profile else None
         self.lib.call("zt_conv2d_nhwc_bf16_variant", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin,
                       wdev.data_ptr() + 2 * w_roff * ldk, CoutP, ldk, bias, yptr, ldy, mode, Cout, KH, KW, stride, pad[0], pad[1],
                       ACT[act], float(alpha), auxp, ldaux, epi, variant, self._s(x.t))
-        if timed:
-            e1.record()
-            prof["events"].append((e0, e1))
+        self._ev_end(tok)
         return out
 
     def conv2d_wgrad_bf16(self, x, dz, Cout, KH, KW, grad_w, accumulate=False, slab=None, grad_b=None):

@@ -64,8 +64,28 @@ class ClipAdam:
         import torch.distributed as dist
         return dist.get_world_size(self.pg) if dist.is_available() and dist.is_initialized() else 1
 
+    def _check_binding(self):
+        """The parameters and their .grad must still be views of the flat bucket (they stop being so after `model.to()/.cuda()`,
+        `model.zero_grad(set_to_none=True)` or `p.grad = None`).  Stray gradients are copied back into the bucket and re-bound;
+        parameters that moved cannot be repaired silently (Adam moments belong to the old storage): that is an error."""
+        fp = self.fp
+        if not fp.intact():
+            raise RuntimeError("ClipAdam: the model's parameters no longer live in the optimizer's flat bucket (model.to()/.cuda() "
+                               "after the optimizer was built?); build the optimizer after moving the model")
+        base = fp.grad.data_ptr()
+        for p, o, s in zip(fp.params, fp.offsets, fp.sizes):
+            view = fp.grad[o:o + s].view(p.shape)
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != base + 4 * o:
+                view.copy_(p.grad)
+            else:
+                continue
+            p.grad = view
+
     def step(self):
         import torch.distributed as dist
+        self._check_binding()
         fp = self.fp
         ws = self.world()
         if ws > 1:
@@ -76,3 +96,59 @@ class ClipAdam:
                  float(self.param_groups[0]["lr"]), self.betas[0], self.betas[1], self.eps, self.wd, self.t, self.gnorm,
                  current_stream(fp.flat.device))
         return self.gnorm
+
+
+class TrainStep:
+    """One iteration of the reference loop (train.py:119-131) as a callable: `loss = step(frame, is_new_seq)`.
+
+    use_graph=False: eager launches (~550 kernel launches through ctypes per step).
+    use_graph=True : the steady-state step (zero_grad + forward incl. RAFT + loss + backward into the flat gradient bucket) is
+    captured ONCE into a hipGraph on first use and replayed afterwards -- the launch-bound host loop (~14 us x 550 launches)
+    becomes one graph launch.  The frame is copied into a static input buffer (host -> HBM or HBM -> HBM) and the recurrent
+    cache `last_H3 / last_s3` lives in static buffers, so the captured addresses stay valid from frame to frame.  New-sequence
+    frames (rare: once per clip) and the gradient all-reduce + clip + Adam launch (which takes the host-side step count) stay
+    eager.  The model must not be moved, and `last_H3 / last_s3` must not be re-assigned by the caller, after the capture."""
+
+    def __init__(self, model, optimizer, use_graph=True):
+        self.model, self.opt, self.use_graph = model, optimizer, use_graph
+        self.graph, self.x, self.loss, self.n_eager_steady = None, None, None, 0
+
+    def _body(self, x):
+        """zero_grad + loss + gradients straight into the optimizer's flat bucket (no autograd bookkeeping, no ATen math)"""
+        opt = self.opt
+        opt._check_binding()
+        loss, _ = self.model._loss_and_grads(x, into=opt.fp.grad)
+        return loss.reshape(())
+
+    def __call__(self, frame, is_new_seq=False):
+        import torch
+        m = self.model
+        m.is_new_seq = bool(is_new_seq)
+        dev = self.opt.fp.flat.device
+        if not self.use_graph:
+            with torch.no_grad():
+                loss = self._body(frame.to(dev, non_blocking=True))
+            self.opt.step()
+            return loss
+        if self.x is None:
+            self.x = torch.empty(frame.shape, dtype=torch.float32, device=dev)
+            m.enable_static_cache(frame.shape)
+        self.x.copy_(frame, non_blocking=True)
+        if is_new_seq or m.last_H3 is None or self.n_eager_steady < 1:
+            # eager: new-sequence frames, and the first steady-state frame (loads every kernel's code object, sizes the slabs and
+            # the plan's persistent buffers before anything is captured)
+            if not (is_new_seq or m.last_H3 is None):
+                self.n_eager_steady += 1
+            with torch.no_grad():
+                loss = self._body(self.x)
+            self.opt.step()
+            return loss
+        if self.graph is None:
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.loss = self._body(self.x)
+            self.graph = g
+        self.graph.replay()
+        self.opt.step()
+        return self.loss

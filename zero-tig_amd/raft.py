@@ -135,47 +135,83 @@ class RaftPlan:
         HX = self._new(1, h, w, 384, zero=True)                              # [net | inp | motion(126) | flow(2)]
         self._conv(CV(c), "cnet.conv2", 128, 1, act="tanh", out=CV(HX, 0, 128))
         self._conv(CV(c), "cnet.conv2", 128, 1, act="relu", out=CV(HX, 128, 128), row0=128)
-        coords1 = self._new(npx, 2, dtype=torch.float32)
-        lib.call("zt_raft_coords_init_f32", coords1, h, w, s)
-        F4 = self._new(1, h, w, 4, dtype=torch.float32, zero=True)           # fp32 flow for the up-sampler
-        ldfin = 8 if self.h else 4
-        FIN = self._new(1, h, w, ldfin, zero=True)                           # flow as the 7x7 conv input
-        es = HX.element_size()
-        lib.call("zt_raft_flow_step", coords1, None, 0, h, w, F4, 4, HX.data_ptr() + es * 382, 384, FIN, ldfin, dt, s)
-        CF, RH = self._new(1, h, w, 256), self._new(1, h, w, 128)
-        CORR = self._new(1, h, w, 328 if self.h else 324, zero=True)
-        e, g = "update_block.encoder.", "update_block.gru."
+        st = self.new_state(h, w, HX)
+        st.corr0, st.levels = corr0, levels
         aux = {}
         for it in range(iters):
-            o.corr_lookup(corr0, levels, h, w, coords1, out=CORR)
+            self.refine_step(st)
             if want_aux and it == 0:
-                aux["corr0"] = CORR.clone()
-            cor1 = self._conv(CV(CORR, 0, 324), e + "convc1", 256, 1, act="relu")
-            self._conv(cor1, e + "convc2", 192, 3, act="relu", out=CV(CF, 0, 192))
-            flo1 = self._conv(CV(FIN, 0, 2), e + "convf1", 128, 7, act="relu")
-            self._conv(flo1, e + "convf2", 64, 3, act="relu", out=CV(CF, 192, 64))
-            self._conv(CF, e + "conv", 126, 3, act="relu", out=CV(HX, 256, 126))
-            for sfx, k, pad in (("1", (1, 5), (0, 2)), ("2", (5, 1), (2, 0))):
-                zr = self._conv(HX, g + "convzr" + sfx, 256, k, pad=pad, act="sigmoid")
-                lib.call("zt_gru_rh", zr, dt, 256, HX, 384, RH, 128, 128, npx, s)
-                q = self._conv(CV(RH), g + "convq" + sfx, 128, k, pad=pad, act="tanh", x2=CV(HX, 128, 256))
-                lib.call("zt_gru_update", zr, dt, 256, q, 128, HX, 384, 128, npx, s)
-            fh = self._conv(CV(HX, 0, 128), "update_block.flow_head.conv1", 256, 3, act="relu")
-            delta = self._conv(fh, "update_block.flow_head.conv2", 2, 3, out_f32=True)       # fp32 [..,4]
-            lib.call("zt_raft_flow_step", coords1, delta, delta.shape[-1], h, w, F4, 4, HX.data_ptr() + es * 382, 384, FIN, ldfin, dt, s)
-        m1 = self._conv(CV(HX, 0, 128), "update_block.mask.0", 256, 3, act="relu")
-        mask = self._conv(m1, "update_block.mask.2", 576, 1, alpha=0.25, out_f32=True)
-        flow_up = self._new(1, 2, Hp, Wp, dtype=torch.float32)
-        flow_low = self._new(1, 2, h, w, dtype=torch.float32)
-        lib.call("zt_convex_upsample_f32", F4, 4, mask, 576, flow_up, flow_low, h, w, s)
+                aux["corr0"] = st.CORR.clone()
+        flow_low, flow_up, mask = self.finish(st, Hp, Wp)
         if want_aux:
             aux.update(fmap1=fmap1, fmap2=fmap2, HX=HX, mask=mask)
             return flow_low, flow_up, aux
         return flow_low, flow_up
 
-    def update_cache(self, last_H3, last_s3, L2, of_scale, want_aux=False):
-        """model.py:221-259: down-scale, equalise the current frame, RAFT(12), backward-warp both cached tensors."""
+    # ---- the refinement loop of raft.py:112-126, one iteration at a time (tests drive a single step against the golden) ----
+    class State:
+        pass
+
+    def new_state(self, h, w, HX, coords=None):
+        """Buffers of the refinement loop.  HX: [1,h,w,384] = [net | inp | motion(126) | flow(2)] with net / inp filled in.
+        coords: optional [h*w,2] starting coordinates (x, y); default = the pixel grid (zero flow, raft.py:107)."""
+        lib, dt, s = self.lib, self.dt, current_stream(self.dev)
+        st = RaftPlan.State()
+        st.h, st.w, st.npx, st.HX = h, w, h * w, HX
+        st.coords1 = self._new(st.npx, 2, dtype=torch.float32)
+        lib.call("zt_raft_coords_init_f32", st.coords1, h, w, s)
+        st.F4 = self._new(1, h, w, 4, dtype=torch.float32, zero=True)        # fp32 flow for the up-sampler
+        st.ldfin = 8 if self.h else 4
+        st.FIN = self._new(1, h, w, st.ldfin, zero=True)                     # flow as the 7x7 conv input
+        st.es = HX.element_size()
+        delta, ldd = None, 0
+        if coords is not None:                                               # flow = coords - grid, applied as a first "delta"
+            delta = torch.zeros((st.npx, 4), dtype=torch.float32, device=self.dev)
+            delta[:, :2] = coords.to(self.dev) - st.coords1
+            ldd = 4
+        lib.call("zt_raft_flow_step", st.coords1, delta, ldd, h, w, st.F4, 4, HX.data_ptr() + st.es * 382, 384, st.FIN, st.ldfin, dt, s)
+        st.CF, st.RH = self._new(1, h, w, 256), self._new(1, h, w, 128)
+        st.CORR = self._new(1, h, w, 328 if self.h else 324, zero=True)
+        st.delta = None
+        return st
+
+    def refine_step(self, st):
+        """corr lookup (corr.py:29-50) -> BasicUpdateBlock (update.py:114-136, mask head deferred to finish()) -> coords1 += delta."""
+        o, lib, dt, s = self.ops, self.lib, self.dt, current_stream(self.dev)
+        h, w, npx, HX, CF, RH, CORR = st.h, st.w, st.npx, st.HX, st.CF, st.RH, st.CORR
+        e, g = "update_block.encoder.", "update_block.gru."
+        o.corr_lookup(st.corr0, st.levels, h, w, st.coords1, out=CORR)
+        cor1 = self._conv(CV(CORR, 0, 324), e + "convc1", 256, 1, act="relu")
+        self._conv(cor1, e + "convc2", 192, 3, act="relu", out=CV(CF, 0, 192))
+        flo1 = self._conv(CV(st.FIN, 0, 2), e + "convf1", 128, 7, act="relu")
+        self._conv(flo1, e + "convf2", 64, 3, act="relu", out=CV(CF, 192, 64))
+        self._conv(CF, e + "conv", 126, 3, act="relu", out=CV(HX, 256, 126))
+        for sfx, k, pad in (("1", (1, 5), (0, 2)), ("2", (5, 1), (2, 0))):
+            zr = self._conv(HX, g + "convzr" + sfx, 256, k, pad=pad, act="sigmoid")
+            lib.call("zt_gru_rh", zr, dt, 256, HX, 384, RH, 128, 128, npx, s)
+            q = self._conv(CV(RH), g + "convq" + sfx, 128, k, pad=pad, act="tanh", x2=CV(HX, 128, 256))
+            lib.call("zt_gru_update", zr, dt, 256, q, 128, HX, 384, 128, npx, s)
+        fh = self._conv(CV(HX, 0, 128), "update_block.flow_head.conv1", 256, 3, act="relu")
+        st.delta = self._conv(fh, "update_block.flow_head.conv2", 2, 3, out_f32=True)       # fp32 [..,4]
+        lib.call("zt_raft_flow_step", st.coords1, st.delta, st.delta.shape[-1], h, w, st.F4, 4, HX.data_ptr() + st.es * 382, 384,
+                 st.FIN, st.ldfin, dt, s)
+
+    def finish(self, st, Hp, Wp):
+        """mask head (update.py:122-125, 134) on the final hidden state + convex 8x up-sampling (raft.py:64-75)."""
+        HX, h, w = st.HX, st.h, st.w
+        m1 = self._conv(CV(HX, 0, 128), "update_block.mask.0", 256, 3, act="relu")
+        mask = self._conv(m1, "update_block.mask.2", 576, 1, alpha=0.25, out_f32=True)
+        flow_up = self._new(1, 2, Hp, Wp, dtype=torch.float32)
+        flow_low = self._new(1, 2, h, w, dtype=torch.float32)
+        self.lib.call("zt_convex_upsample_f32", st.F4, 4, mask, 576, flow_up, flow_low, h, w, current_stream(self.dev))
+        return flow_low, flow_up, mask
+
+    def update_cache(self, last_H3, last_s3, L2, of_scale, want_aux=False, flow_up=None):
+        """model.py:221-259: down-scale, equalise the current frame, RAFT(12), backward-warp both cached tensors.
+        flow_up: parity tests only -- warp with this [1,2,Hp,Wp] flow (the oracle's) instead of running RAFT."""
         o = self.ops
+        if flow_up is not None:
+            return o.warp2(flow_up.contiguous(), last_H3.contiguous(), last_s3.contiguous())
         _, _, H, W = last_H3.shape
         ht, wd = H // of_scale, W // of_scale
         a = o.resize_bilinear(last_H3.contiguous(), ht, wd, 255.0)
