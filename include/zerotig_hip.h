@@ -61,6 +61,14 @@ int zt_conv2d_nhwc_f32(const float* x, const float* x2, int csplit, int ldx, int
                        const float* w, int ldw, const float* bias, float* y, int ldy, int out_planar, int Cout, int KH,
                        int KW, int stride, int padH, int padW, int act, float alpha, const float* aux, int ldaux,
                        int epi, zt_stream_t stream);
+/* same with the fused SepConvGRU epilogues of model/RAFT/update.py:42-58 (nhwc output only):
+ * epi 4: [z | r] = act(conv): channels < esplit are stored to y; channels >= esplit leave as r * h to y2 [..][ldy2] at channel
+ *        co - esplit (aux = h, nhwc ldaux)                                    == `torch.cat`-free `r * h` of update.py:44/52
+ * epi 5: q = act(conv): y (= h, read and written in place) <- (1 - z) * h + z * q, aux = z   == update.py:46/54 */
+int zt_conv2d_nhwc_f32_ex(const float* x, const float* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
+                          const float* w, int ldw, const float* bias, float* y, int ldy, int out_planar, int Cout, int KH,
+                          int KW, int stride, int padH, int padW, int act, float alpha, const float* aux, int ldaux,
+                          int epi, float* y2, int ldy2, int esplit, zt_stream_t stream);
 /* weight gradient of a stride-1 "same" conv (autograd of the above): grad_w [Cout][Cin][KH][KW] (torch layout)
  * (+)= sum_p x[p+tap][ci] dz[p][co]; grad_b [Cout] (optional) (+)= sum_p dz[p][co] (bias gradient, folded into the same pass);
  * slab: workspace for per-workgroup partials (deterministic reduction). */
@@ -201,6 +209,11 @@ int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, int ldx, int 
 int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin, const void* w,
                                 int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout, int KH, int KW, int stride,
                                 int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi, int variant, zt_stream_t stream);
+/* bf16 twin of zt_conv2d_nhwc_f32_ex (epi 4 / 5: bf16 nhwc outputs, tiled kernel) */
+int zt_conv2d_nhwc_bf16_ex(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin, const void* w,
+                           int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout, int KH, int KW, int stride,
+                           int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi, void* y2, int ldy2, int esplit,
+                           zt_stream_t stream);
 int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout, int KH, int KW,
                               float* slab, size_t slab_bytes, float* grad_w, float* grad_b, int accumulate, zt_stream_t stream);
 int zt_repack_conv_weight_bf16(const float* src, void* dst, int Cout, int Cin, int KH, int KW, int CoutP, int ldk, int co_off,

@@ -304,7 +304,8 @@ def test_raft_ops_golden(backend, oracle, synth):
     assert torch.equal(look2.cpu().permute(0, 3, 1, 2), oracle.corr_lookup(pyr, coords))
 
 
-def test_raft_update_step_golden(backend, oracle, synth):
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_raft_update_step_golden(backend, oracle, synth, precision):
     """One BasicUpdateBlock step (update.py:114-136) through the plan's HIP kernels -- fused 4-level lookup, motion encoder,
     SepConvGRU x2, flow head, mask head, convex up-sampling -- against the reference's own `ub_net` / `ub_dflow` / `ub_mask` /
     `ub_up` (golden g6: `net.raft.update_block(h, inp, corr, flow)` and `upsample_flow`)."""
@@ -315,7 +316,8 @@ def test_raft_update_step_golden(backend, oracle, synth):
     raft_mod = importlib.import_module("zero-tig_amd.raft")
     st = synth.make_state(3)
     W = {k: torch.from_numpy(np.array(v)).to(dev) for k, v in st.items() if k.startswith("raft.")}
-    plan = raft_mod.RaftPlan(ops, W, dev)
+    plan = raft_mod.RaftPlan(ops, W, dev, precision=precision)
+    bf = precision == "bf16"      # throughput mode: bf16 storage of activations / weights (3 significant digits), fp32 accumulation
     h, w = 16, 24
     hh = torch.tanh(torch.from_numpy(synth.normal("ops.h", (1, 128, h, w), 0.0, 1.0, 7)))
     inp = torch.relu(torch.from_numpy(synth.normal("ops.inp", (1, 128, h, w), 0.0, 1.0, 7)))
@@ -324,17 +326,23 @@ def test_raft_update_step_golden(backend, oracle, synth):
     coords = torch.from_numpy(g["lookup_coords"])
     HX = torch.zeros(1, h, w, 384)
     HX[..., :128], HX[..., 128:256] = _nhwc(hh), _nhwc(inp)
-    state = plan.new_state(h, w, HX.to(dev), coords=coords[0].permute(1, 2, 0).reshape(-1, 2).contiguous())
+    state = plan.new_state(h, w, HX.to(dev).to(plan.adt), coords=coords[0].permute(1, 2, 0).reshape(-1, 2).contiguous())
     state.corr0 = ops.conv2d(CV(_nhwc(f1).to(dev)), f2.view(1, 256, h * w).to(dev).contiguous(), None, h * w, 1, 1, alpha=1.0 / 16.0)
     state.levels = ops.corr_pyramid(state.corr0, h, w)
     plan.refine_step(state)
-    net_out = state.HX.cpu()[..., :128].permute(0, 3, 1, 2)
-    assert maxerr(net_out, torch.from_numpy(g["ub_net"])) < 5e-5, maxerr(net_out, torch.from_numpy(g["ub_net"]))
+    net_out = state.HX.float().cpu()[..., :128].permute(0, 3, 1, 2)
+    e = maxerr(net_out, torch.from_numpy(g["ub_net"]))
+    assert e < (1.5e-2 if bf else 5e-6), e
     dfl = state.delta.cpu()[..., :2].permute(0, 3, 1, 2)
-    assert maxerr(dfl, torch.from_numpy(g["ub_dflow"])) < 1e-4, maxerr(dfl, torch.from_numpy(g["ub_dflow"]))
+    e = maxerr(dfl, torch.from_numpy(g["ub_dflow"]))
+    assert e < (4e-3 if bf else 2e-6), e
     _, flow_up, mask = plan.finish(state, 8 * h, 8 * w)
-    assert maxerr(mask.cpu().permute(0, 3, 1, 2)[:, ::9], torch.from_numpy(g["ub_mask"])) < 1e-4
-    assert maxerr(flow_up, torch.from_numpy(g["ub_up"])) < 2e-4, maxerr(flow_up, torch.from_numpy(g["ub_up"]))
+    e = maxerr(mask.cpu().permute(0, 3, 1, 2)[:, ::9], torch.from_numpy(g["ub_mask"]))
+    assert e < (1e-3 if bf else 1e-6), e
+    e = maxerr(flow_up, torch.from_numpy(g["ub_up"]))
+    assert e < (2e-2 if bf else 5e-5), e
+    if bf:
+        return
     # and the up-sampler alone on the ORACLE's mask / flow (isolates raft.py:64-75)
     fl = coords - torch.stack(torch.meshgrid(torch.arange(w), torch.arange(h), indexing="xy"), 0).float()[None]
     pyr = oracle.corr_pyramid(f1, f2)

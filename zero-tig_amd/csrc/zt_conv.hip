@@ -28,6 +28,8 @@ struct ConvArgs {
   int act, epi, out_planar;
   float alpha;
   int tilesX, tilesY;
+  float* y2;                   // epi 4: second destination (r * h), channels [esplit, Cout) go there
+  int ldy2, esplit;
 };
 
 constexpr int TH = 4, TW = 32, CK = 16;
@@ -161,6 +163,16 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(ConvArgs a) {
         if (ox >= a.Wo) continue;
         float v = apply_act(a.alpha * (acc[m][q][j] + b), a.act);
         const size_t pix = (size_t)(n * a.Ho + oy) * a.Wo + ox;
+        if (a.epi >= 4) {       // SepConvGRU fusions (update.py:42-58), nhwc only
+          if (a.epi == 4) {     // [z | r] = sigmoid(conv): z is stored, r leaves as r * h
+            if (co < a.esplit) a.y[pix * a.ldy + co] = v;
+            else a.y2[pix * a.ldy2 + co - a.esplit] = v * a.aux[pix * a.ldaux + co - a.esplit];
+          } else {              // q = tanh(conv): h = (1 - z) * h + z * q in place (aux = z)
+            const float z = a.aux[pix * a.ldaux + co], hv = a.y[pix * a.ldy + co];
+            a.y[pix * a.ldy + co] = (1.f - z) * hv + z * v;
+          }
+          continue;
+        }
         if (a.epi) {
           float u = a.aux[pix * a.ldaux + co];
           if (a.epi == 1) v *= (u > 0.f ? 1.f : 0.2f);
@@ -389,6 +401,8 @@ struct ConvArgsH {
   int dbg;                     // tuning ablations (tools/bench_conv.py): 1 skip MFMA loop, 2 skip epilogue, 4 skip prefetch
   float alpha;
   int tilesX, tilesY;
+  zt_bf16* y2;                 // epi 4: second destination (r * h), channels [esplit, Cout) go there
+  int ldy2, esplit;
 };
 
 constexpr int HCK = 32;                 // channel granularity of a two-part (split) input
@@ -397,8 +411,12 @@ constexpr int HCK = 32;                 // channel granularity of a two-part (sp
 // otherwise weights are staged per kernel row (7x7).  MT = 16-pixel MFMA tiles per wave along x (1 for small feature maps).
 // CH2 = 32-channel MFMA K-steps per staged chunk: 2 (64 channels, 160-byte rows) halves the barrier / staging rounds of the
 // latency-bound small-map layers whose Cin is a multiple of 64.
-template <int KH, int KW, int S, int NT, int MT, bool ALL, int CH2>
+// PD = chunks of global loads in flight (register slots).  The small RAFT maps (45 x 80) are a serial chain of short kernels whose
+// MFMA work per chunk (~0.2 us) cannot cover a global latency (~1-2 us): with PD = 3 nearly the whole K range is requested
+// before the first MFMA instead of one latency being exposed per chunk.
+template <int KH, int KW, int S, int NT, int MT, bool ALL, int CH2, int PD>
 __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
+  static_assert(ALL || PD == 1, "per-row weight groups are staged inside the chunk");
   constexpr int KCH = 32 * CH2, KCHP = CH2 == 2 ? 80 : 48, CPP = 4 * CH2;      // channels / LDS pitch / 16-byte chunks per pixel
   constexpr int TWm = 16 * MT;
   constexpr int IR = (TH - 1) * S + KH, IC = (TWm - 1) * S + KW;
@@ -429,8 +447,9 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
   // issued before this chunk's MFMAs, so one global latency is exposed per launch rather than several per chunk.
   constexpr int NWS = (TG * NT * 16 * CPP + 255) / 256;
   constexpr int NXS = (IR * IC * CPP + 255) / 256;
-  uint4 wv[NWS], xv[NXS];
-  auto load_w = [&](int c0, int grp) {
+  uint4 wv[PD][NWS], xv[PD][NXS];
+  auto load_w = [&](auto sl, int c0, int grp) {
+    constexpr int d = decltype(sl)::value;
 #pragma unroll
     for (int i = 0; i < NWS; ++i) {
       const int e = tid + i * 256;
@@ -440,20 +459,22 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
       tap = tap < KH * KW ? tap : KH * KW - 1;
       const int c = c0 + q * 8;
       const int cor = co0 + co < a.CoutP ? co0 + co : a.CoutP - 1;
-      wv[i] = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.CoutP + cor) * a.ldk + (c < a.ldk ? c : 0));
+      wv[d][i] = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.CoutP + cor) * a.ldk + (c < a.ldk ? c : 0));
     }
   };
-  auto write_w = [&](int c0) {
+  auto write_w = [&](auto sl, int c0) {
+    constexpr int d = decltype(sl)::value;
 #pragma unroll
     for (int i = 0; i < NWS; ++i) {
       const int e = tid + i * 256;
       const int q = e % CPP, r = e / CPP;
       const int co = r % (NT * 16), tl = r / (NT * 16);
       const bool ok = c0 + q * 8 < a.ldk && co0 + co < a.CoutP;
-      if (e < TG * NT * 16 * CPP) *reinterpret_cast<uint4*>(ws + (tl * NT * 16 + co) * KCHP + q * 8) = ok ? wv[i] : make_uint4(0u, 0u, 0u, 0u);
+      if (e < TG * NT * 16 * CPP) *reinterpret_cast<uint4*>(ws + (tl * NT * 16 + co) * KCHP + q * 8) = ok ? wv[d][i] : make_uint4(0u, 0u, 0u, 0u);
     }
   };
-  auto load_x = [&](int c0) {
+  auto load_x = [&](auto sl, int c0) {
+    constexpr int d = decltype(sl)::value;
     const bool second = a.x2 != nullptr && c0 >= a.csplit;
     const zt_bf16* src = second ? a.x2 : a.x;
     const int ld = second ? a.ldx2 : a.ldx;
@@ -466,10 +487,11 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
       gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
       gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
       const int c = cbase + q * 8;
-      xv[i] = *reinterpret_cast<const uint4*>(src + (size_t)((n * a.H + gy) * a.W + gx) * ld + (c < ld ? c : 0));
+      xv[d][i] = *reinterpret_cast<const uint4*>(src + (size_t)((n * a.H + gy) * a.W + gx) * ld + (c < ld ? c : 0));
     }
   };
-  auto write_x = [&](int c0) {
+  auto write_x = [&](auto sl, int c0) {
+    constexpr int d = decltype(sl)::value;
     const bool second = a.x2 != nullptr && c0 >= a.csplit;
     const int cbase = second ? c0 - a.csplit : c0;
     const int climit = second ? a.Cin - a.csplit : (a.x2 ? a.csplit : a.Cin);
@@ -482,7 +504,7 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
       const int nv = climit - (cbase + q * 8);                  // valid channels of this 8-chunk (ragged tail / beyond the input)
       const unsigned m0 = nv >= 2 ? ~0u : (nv == 1 ? 0xFFFFu : 0u), m1 = nv >= 4 ? ~0u : (nv == 3 ? 0xFFFFu : 0u);
       const unsigned m2 = nv >= 6 ? ~0u : (nv == 5 ? 0xFFFFu : 0u), m3 = nv >= 8 ? ~0u : (nv == 7 ? 0xFFFFu : 0u);
-      uint4 v = xv[i];
+      uint4 v = xv[d][i];
       v.x = in ? (v.x & m0) : 0u;
       v.y = in ? (v.y & m1) : 0u;
       v.z = in ? (v.z & m2) : 0u;
@@ -491,44 +513,56 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
     }
   };
 
-  load_x(0);
-  load_w(0, 0);
-  for (int c0 = 0; c0 < a.Cin; c0 += KCH) {
-    __syncthreads();
-    write_x(c0);
-    write_w(c0);
-    __syncthreads();
-    const bool more = c0 + KCH < a.Cin;
-    if (more) load_x(c0 + KCH);
-    if (ALL && more) load_w(c0 + KCH, 0);                       // single tap group: its weights are prefetched as well
-#pragma unroll 1
-    for (int grp = 0; grp < NG; ++grp) {
-      if (grp > 0) {                                            // per-kernel-row weight groups (7x7): staged inside the chunk
-        __syncthreads();
-        load_w(c0, grp);
-        write_w(c0);
-        __syncthreads();
-      }
-#pragma unroll
-      for (int tl = 0; tl < TG; ++tl) {
-        const int ky = ALL ? tl / KW : grp, kx = ALL ? tl % KW : tl;
-#pragma unroll
-        for (int kc = 0; kc < CH2; ++kc) {
-          zt_s16x8 av[MT], bv[NT];
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            av[m] = *reinterpret_cast<const zt_s16x8*>(xs + ((wave * S + ky) * IC + (m * 16 + l15) * S + kx) * KCHP + kc * 32 + 8 * l4);
-#pragma unroll
-          for (int q = 0; q < NT; ++q)
-            bv[q] = *reinterpret_cast<const zt_s16x8*>(ws + (tl * NT * 16 + q * 16 + l15) * KCHP + kc * 32 + 8 * l4);
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(av[m], bv[q], acc[m][q]);
-        }
-      }
+  zt_static_for<0, PD>([&](auto sl) {
+    constexpr int d = decltype(sl)::value;
+    if (d * KCH < a.Cin) {
+      load_x(sl, d * KCH);
+      load_w(sl, d * KCH, 0);
     }
-    if (!ALL && more) load_w(c0 + KCH, 0);
+  });
+  for (int cb = 0; cb < a.Cin; cb += PD * KCH) {
+    zt_static_for<0, PD>([&](auto sl) {
+      constexpr int d = decltype(sl)::value;
+      const int c0 = cb + d * KCH;
+      if (c0 < a.Cin) {                                           // uniform
+        __syncthreads();
+        write_x(sl, c0);
+        write_w(sl, c0);
+        __syncthreads();
+        const int cn = c0 + PD * KCH;
+        const bool more = cn < a.Cin;
+        if (more) load_x(sl, cn);
+        if (ALL && more) load_w(sl, cn, 0);                       // single tap group: its weights are prefetched as well
+#pragma unroll 1
+        for (int grp = 0; grp < NG; ++grp) {
+          if (grp > 0) {                                          // per-kernel-row weight groups (7x7): staged inside the chunk
+            __syncthreads();
+            load_w(sl, c0, grp);
+            write_w(sl, c0);
+            __syncthreads();
+          }
+#pragma unroll
+          for (int tl = 0; tl < TG; ++tl) {
+            const int ky = ALL ? tl / KW : grp, kx = ALL ? tl % KW : tl;
+#pragma unroll
+            for (int kc = 0; kc < CH2; ++kc) {
+              zt_s16x8 av[MT], bv[NT];
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+                av[m] = *reinterpret_cast<const zt_s16x8*>(xs + ((wave * S + ky) * IC + (m * 16 + l15) * S + kx) * KCHP + kc * 32 + 8 * l4);
+#pragma unroll
+              for (int q = 0; q < NT; ++q)
+                bv[q] = *reinterpret_cast<const zt_s16x8*>(ws + (tl * NT * 16 + q * 16 + l15) * KCHP + kc * 32 + 8 * l4);
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(av[m], bv[q], acc[m][q]);
+            }
+          }
+        }
+        if (!ALL && more) load_w(sl, cn, 0);
+      }
+    });
   }
 
   const int oy = oy0 + wave;
@@ -546,6 +580,17 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
         if (ox >= a.Wo) continue;
         float v = apply_act(a.alpha * (acc[m][q][j] + b), a.act);
         const size_t pix = (size_t)(n * a.Ho + oy) * a.Wo + ox;
+        if (a.epi >= 4) {       // SepConvGRU fusions (update.py:42-58), bf16 nhwc only
+          zt_bf16* yb = (zt_bf16*)a.y;
+          if (a.epi == 4) {     // [z | r] = sigmoid(conv): z is stored, r leaves as r * h
+            if (co < a.esplit) yb[pix * a.ldy + co] = zt_f2bf(v);
+            else a.y2[pix * a.ldy2 + co - a.esplit] = zt_f2bf(v * zt_bf2f(a.aux[pix * a.ldaux + co - a.esplit]));
+          } else {              // q = tanh(conv): h = (1 - z) * h + z * q in place (aux = z)
+            const float z = zt_bf2f(a.aux[pix * a.ldaux + co]), hv = zt_bf2f(yb[pix * a.ldy + co]);
+            yb[pix * a.ldy + co] = zt_f2bf((1.f - z) * hv + z * v);
+          }
+          continue;
+        }
         if (a.epi) {
           float u = zt_bf2f(a.aux[pix * a.ldaux + co]);
           if (a.epi == 1) v *= (u > 0.f ? 1.f : 0.2f);
@@ -568,6 +613,8 @@ int launch_conv_h(const ConvArgsH& a, int NT, unsigned gx, hipStream_t stream) {
   constexpr int IRc = (TH - 1) * S + KH, ICc = (16 * MT - 1) * S + KW;
   // 64-channel chunks where every chunk is full: Cin (and the split point of a two-part input) multiples of 64
   const bool wide = a.Cin % 64 == 0 && (!a.x2 || a.csplit % 64 == 0);
+  // latency-bound launches (about two workgroups per CU or fewer, several channel chunks): three chunks of loads in flight
+  const bool deep = MT == 1 && (long long)grid.x * grid.y <= 1024 && a.Cin > 64;
 #define ZT_CH(nt)                                                                                             \
   {                                                                                                           \
     constexpr bool all1 = (KH * KW * nt * 16 + IRc * ICc) * 48 * 2 <= 72 * 1024;                              \
@@ -575,11 +622,23 @@ int launch_conv_h(const ConvArgsH& a, int NT, unsigned gx, hipStream_t stream) {
     constexpr bool fits2 = all2;              /* only while >= 2 workgroups still fit a CU: larger tiles lose more than they gain */ \
     if constexpr (fits2) {                                                                                    \
       if (wide) {                                                                                             \
-        hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all2, 2>), grid, block, 0, stream, a);   \
+        if constexpr (MT == 1) {                                                                              \
+          if (deep) {                                                                                         \
+            hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all2, 2, 3>), grid, block, 0, stream, a); \
+            break;                                                                                            \
+          }                                                                                                   \
+        }                                                                                                     \
+        hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all2, 2, 1>), grid, block, 0, stream, a); \
         break;                                                                                                \
       }                                                                                                       \
     }                                                                                                         \
-    hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all1, 1>), grid, block, 0, stream, a);       \
+    if constexpr (MT == 1 && all1) {                                                                          \
+      if (deep) {                                                                                             \
+        hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all1, 1, 3>), grid, block, 0, stream, a); \
+        break;                                                                                                \
+      }                                                                                                       \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all1, 1, 1>), grid, block, 0, stream, a);    \
   }
   switch (NT) {
     case 1: ZT_CH(1) break;
@@ -1578,11 +1637,12 @@ __global__ void __launch_bounds__(256) repack_w_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int zt_conv2d_nhwc_f32(const float* x, const float* x2, int csplit, int ldx, int ldx2, int N, int H, int W,
-                                  int Cin, const float* w, int ldw, const float* bias, float* y, int ldy, int out_planar,
-                                  int Cout, int KH, int KW, int stride, int padH, int padW, int act, float alpha,
-                                  const float* aux, int ldaux, int epi, hipStream_t stream) {
+extern "C" int zt_conv2d_nhwc_f32_ex(const float* x, const float* x2, int csplit, int ldx, int ldx2, int N, int H, int W,
+                                     int Cin, const float* w, int ldw, const float* bias, float* y, int ldy, int out_planar,
+                                     int Cout, int KH, int KW, int stride, int padH, int padW, int act, float alpha,
+                                     const float* aux, int ldaux, int epi, float* y2, int ldy2, int esplit, hipStream_t stream) {
   ZT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  ZT_REQUIRE(epi >= 0 && epi <= 5 && (epi < 4 || !out_planar) && (epi != 4 || (y2 && esplit > 0 && esplit < Cout)));
   ZT_REQUIRE(ldx % 4 == 0 && ldw % 16 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
   ZT_REQUIRE(!x2 || (csplit % CK == 0 && ldx2 % 4 == 0 && ((uintptr_t)x2 & 15) == 0));
   ZT_REQUIRE(epi == 0 || aux);
@@ -1593,6 +1653,7 @@ extern "C" int zt_conv2d_nhwc_f32(const float* x, const float* x2, int csplit, i
   a.Wo = (W + 2 * padW - KW) / stride + 1;
   a.Cout = Cout; a.ldy = ldy; a.ldw = ldw; a.ldaux = ldaux;
   a.padH = padH; a.padW = padW; a.act = act; a.epi = epi; a.out_planar = out_planar; a.alpha = alpha;
+  a.y2 = y2; a.ldy2 = ldy2; a.esplit = esplit;
   a.tilesX = zt_cdiv(a.Wo, TW);
   a.tilesY = zt_cdiv(a.Ho, TH);
   ZT_REQUIRE(a.Ho > 0 && a.Wo > 0);
@@ -1611,6 +1672,15 @@ extern "C" int zt_conv2d_nhwc_f32(const float* x, const float* x2, int csplit, i
   if (rc) return rc;
   ZT_LAUNCH_CHECK();
   return ZT_OK;
+}
+
+extern "C" int zt_conv2d_nhwc_f32(const float* x, const float* x2, int csplit, int ldx, int ldx2, int N, int H, int W,
+                                  int Cin, const float* w, int ldw, const float* bias, float* y, int ldy, int out_planar,
+                                  int Cout, int KH, int KW, int stride, int padH, int padW, int act, float alpha,
+                                  const float* aux, int ldaux, int epi, hipStream_t stream) {
+  ZT_REQUIRE(epi >= 0 && epi <= 3);
+  return zt_conv2d_nhwc_f32_ex(x, x2, csplit, ldx, ldx2, N, H, W, Cin, w, ldw, bias, y, ldy, out_planar, Cout, KH, KW, stride, padH,
+                               padW, act, alpha, aux, ldaux, epi, nullptr, 0, 0, stream);
 }
 
 extern "C" int zt_conv2d_wgrad_nhwc_f32(const float* x, int ldx, const float* dz, int lddz, int H, int W, int Cin,
@@ -1649,11 +1719,12 @@ extern "C" int zt_repack_conv_weight_f32(const float* src, float* dst, int Cout,
 }
 
 // variant: 0 = choose by problem size, 1 = force the persistent weight-stationary kernel, 2 = force the tiled kernel
-extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
-                                           const void* w, int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode,
-                                           int Cout, int KH, int KW, int stride, int padH, int padW, int act, float alpha,
-                                           const void* aux, int ldaux, int epi, int variant, hipStream_t stream) {
+static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
+                            const void* w, int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode,
+                            int Cout, int KH, int KW, int stride, int padH, int padW, int act, float alpha,
+                            const void* aux, int ldaux, int epi, int variant, void* y2, int ldy2, int esplit, hipStream_t stream) {
   ZT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && out_mode >= 0 && out_mode <= 2);
+  ZT_REQUIRE(epi >= 0 && epi <= 5 && (epi < 4 || (out_mode == 0 && variant == 2)) && (epi != 4 || (y2 && esplit > 0 && esplit < Cout)));
   ZT_REQUIRE(ldx % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
   ZT_REQUIRE(!x2 || (csplit % HCK == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0));
   ZT_REQUIRE(epi == 0 || aux);
@@ -1664,6 +1735,7 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   a.Wo = (W + 2 * padW - KW) / stride + 1;
   a.Cout = Cout; a.CoutP = CoutP; a.ldk = ldk; a.ldy = ldy; a.ldaux = ldaux;
   a.padH = padH; a.padW = padW; a.act = act; a.epi = epi; a.out_mode = out_mode; a.alpha = alpha;
+  a.y2 = (zt_bf16*)y2; a.ldy2 = ldy2; a.esplit = esplit;
   a.dbg = variant >= 32 ? (variant - 32) : (variant >= 16 ? (variant - 16) : 0);   // tuning ablations, see tools/bench_conv.py
   if (variant >= 32) variant = 3;
   if (variant >= 16) variant = 1;
@@ -1729,6 +1801,23 @@ extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int cs
   if (rc) return rc;
   ZT_LAUNCH_CHECK();
   return ZT_OK;
+}
+
+extern "C" int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
+                                           const void* w, int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode,
+                                           int Cout, int KH, int KW, int stride, int padH, int padW, int act, float alpha,
+                                           const void* aux, int ldaux, int epi, int variant, hipStream_t stream) {
+  ZT_REQUIRE(epi >= 0 && epi <= 3);
+  return conv2d_bf16_impl(x, x2, csplit, ldx, ldx2, N, H, W, Cin, w, CoutP, ldk, bias, y, ldy, out_mode, Cout, KH, KW, stride, padH, padW,
+                          act, alpha, aux, ldaux, epi, variant, nullptr, 0, 0, stream);
+}
+
+extern "C" int zt_conv2d_nhwc_bf16_ex(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
+                                      const void* w, int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode,
+                                      int Cout, int KH, int KW, int stride, int padH, int padW, int act, float alpha,
+                                      const void* aux, int ldaux, int epi, void* y2, int ldy2, int esplit, hipStream_t stream) {
+  return conv2d_bf16_impl(x, x2, csplit, ldx, ldx2, N, H, W, Cin, w, CoutP, ldk, bias, y, ldy, out_mode, Cout, KH, KW, stride, padH, padW,
+                          act, alpha, aux, ldaux, epi, epi >= 4 ? 2 : 0, y2, ldy2, esplit, stream);
 }
 
 extern "C" int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,

@@ -177,7 +177,7 @@ class Ops:
         return out
 
     def conv2d(self, x, wdev, bias, Cout, KH, KW, stride=1, pad=(0, 0), act=None, alpha=1.0, x2=None, out=None,
-               out_planar=False, aux=None, epi=0, w_coff=0):
+               out_planar=False, aux=None, epi=0, w_coff=0, out2=None, esplit=0):
         """x: CV/tensor NHWC; optional x2 (CV) supplies channels >= x.C.  out: CV (nhwc) or planar tensor [N,Cout,Ho,Wo]."""
         x = _cv(x)
         Cin, csplit, ldx2, x2p = x.C, 0, 0, None
@@ -206,9 +206,15 @@ class Ops:
             av = _cv(aux)
             auxp, ldaux = av.ptr, av.ld
         tok = self._ev_begin(self.profile["match"].get((KH, KW, stride, Cin, Cout, x.H, x.W))) if self.profile else None
-        self.lib.call("zt_conv2d_nhwc_f32", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin, wdev.data_ptr() + 4 * w_coff, ldw, bias, yptr, ldy,
-                      int(out_planar), Cout, KH, KW, stride, pad[0], pad[1], ACT[act], float(alpha), auxp, ldaux, epi,
-                      self._s(x.t))
+        if epi >= 4:            # fused SepConvGRU epilogues
+            o2 = _cv(out2) if out2 is not None else None
+            self.lib.call("zt_conv2d_nhwc_f32_ex", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin, wdev.data_ptr() + 4 * w_coff, ldw, bias,
+                          yptr, ldy, int(out_planar), Cout, KH, KW, stride, pad[0], pad[1], ACT[act], float(alpha), auxp, ldaux, epi,
+                          o2.ptr if o2 else None, o2.ld if o2 else 0, esplit, self._s(x.t))
+        else:
+            self.lib.call("zt_conv2d_nhwc_f32", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin, wdev.data_ptr() + 4 * w_coff, ldw, bias,
+                          yptr, ldy, int(out_planar), Cout, KH, KW, stride, pad[0], pad[1], ACT[act], float(alpha), auxp, ldaux, epi,
+                          self._s(x.t))
         self._ev_end(tok)
         return out
 
@@ -342,7 +348,7 @@ class Ops:
         return out
 
     def conv2d_bf16(self, x, wdev, bias, Cout, KH, KW, pad=(0, 0), act=None, alpha=1.0, out=None, out_planar=False, aux=None, epi=0,
-                    stride=1, x2=None, out_f32=False, w_roff=0, variant=0):
+                    stride=1, x2=None, out_f32=False, w_roff=0, variant=0, out2=None, esplit=0):
         """x (and optional x2 for channels >= x.C): CV over bf16 NHWC buffers.  out: bf16 NHWC (default), fp32 NHWC (out_f32)
         or fp32 planar [N,Cout,Ho,Wo] (out_planar).  w_roff: first output-channel row of wdev to use."""
         x = _cv(x)
@@ -378,6 +384,14 @@ class Ops:
             assert av.t.dtype == torch.bfloat16
             auxp, ldaux = av.ptr, av.ld
         tok = self._ev_begin(self.profile["match"].get((KH, KW, stride, Cin, Cout, x.H, x.W))) if self.profile else None
+        if epi >= 4:            # fused SepConvGRU epilogues
+            o2 = _cv(out2) if out2 is not None else None
+            assert o2 is None or o2.t.dtype == torch.bfloat16
+            self.lib.call("zt_conv2d_nhwc_bf16_ex", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin,
+                          wdev.data_ptr() + 2 * w_roff * ldk, CoutP, ldk, bias, yptr, ldy, mode, Cout, KH, KW, stride, pad[0], pad[1],
+                          ACT[act], float(alpha), auxp, ldaux, epi, o2.ptr if o2 else None, o2.ld if o2 else 0, esplit, self._s(x.t))
+            self._ev_end(tok)
+            return out
         self.lib.call("zt_conv2d_nhwc_bf16_variant", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin,
                       wdev.data_ptr() + 2 * w_roff * ldk, CoutP, ldk, bias, yptr, ldy, mode, Cout, KH, KW, stride, pad[0], pad[1],
                       ACT[act], float(alpha), auxp, ldaux, epi, variant, self._s(x.t))

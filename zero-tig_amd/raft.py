@@ -61,7 +61,8 @@ class RaftPlan:
                 self.bn[name] = (sc, sh)
 
     # ------------------------------------------------------------------------------------------------ building blocks
-    def _conv(self, x, name, cout, k, stride=1, pad=None, act=None, alpha=1.0, out=None, x2=None, out_f32=False, bias=True, row0=0):
+    def _conv(self, x, name, cout, k, stride=1, pad=None, act=None, alpha=1.0, out=None, x2=None, out_f32=False, bias=True, row0=0,
+              aux=None, epi=0, out2=None, esplit=0):
         """Convolution in the plan's precision.  row0: first output channel of the packed weight to use (1x1 only)."""
         kh, kw = (k, k) if isinstance(k, int) else k
         pad = (kh // 2, kw // 2) if pad is None else pad
@@ -70,8 +71,9 @@ class RaftPlan:
             b = b[row0:]
         if self.h:
             return self.ops.conv2d_bf16(x, self.wd[name], b, cout, kh, kw, pad, act, alpha=alpha, out=out, stride=stride, x2=x2,
-                                        out_f32=out_f32, w_roff=row0)
-        return self.ops.conv2d(x, self.wd[name], b, cout, kh, kw, stride, pad, act, alpha=alpha, out=out, x2=x2, w_coff=row0)
+                                        out_f32=out_f32, w_roff=row0, aux=aux, epi=epi, out2=out2, esplit=esplit)
+        return self.ops.conv2d(x, self.wd[name], b, cout, kh, kw, stride, pad, act, alpha=alpha, out=out, x2=x2, w_coff=row0,
+                               aux=aux, epi=epi, out2=out2, esplit=esplit)
 
     def _norm(self, y, name, kind, inner_relu, res=None, outer_relu=False):
         o = self.ops
@@ -170,7 +172,7 @@ class RaftPlan:
             delta[:, :2] = coords.to(self.dev) - st.coords1
             ldd = 4
         lib.call("zt_raft_flow_step", st.coords1, delta, ldd, h, w, st.F4, 4, HX.data_ptr() + st.es * 382, 384, st.FIN, st.ldfin, dt, s)
-        st.CF, st.RH = self._new(1, h, w, 256), self._new(1, h, w, 128)
+        st.CF, st.RH, st.ZR = self._new(1, h, w, 256), self._new(1, h, w, 128), self._new(1, h, w, 256)
         st.CORR = self._new(1, h, w, 328 if self.h else 324, zero=True)
         st.delta = None
         return st
@@ -187,10 +189,11 @@ class RaftPlan:
         self._conv(flo1, e + "convf2", 64, 3, act="relu", out=CV(CF, 192, 64))
         self._conv(CF, e + "conv", 126, 3, act="relu", out=CV(HX, 256, 126))
         for sfx, k, pad in (("1", (1, 5), (0, 2)), ("2", (5, 1), (2, 0))):
-            zr = self._conv(HX, g + "convzr" + sfx, 256, k, pad=pad, act="sigmoid")
-            lib.call("zt_gru_rh", zr, dt, 256, HX, 384, RH, 128, 128, npx, s)
-            q = self._conv(CV(RH), g + "convq" + sfx, 128, k, pad=pad, act="tanh", x2=CV(HX, 128, 256))
-            lib.call("zt_gru_update", zr, dt, 256, q, 128, HX, 384, 128, npx, s)
+            # z, r = sigmoid(conv[h | x]) with r * h formed in the epilogue; q = tanh(conv[r*h | x]) with the state update
+            # h = (1 - z) h + z q written in place by the epilogue (update.py:42-58): no stand-alone element-wise launches
+            self._conv(HX, g + "convzr" + sfx, 256, k, pad=pad, act="sigmoid", out=st.ZR, aux=CV(HX, 0, 128), epi=4, out2=CV(RH), esplit=128)
+            self._conv(CV(RH), g + "convq" + sfx, 128, k, pad=pad, act="tanh", x2=CV(HX, 128, 256), out=CV(HX, 0, 128),
+                       aux=CV(st.ZR, 0, 128), epi=5)
         fh = self._conv(CV(HX, 0, 128), "update_block.flow_head.conv1", 256, 3, act="relu")
         st.delta = self._conv(fh, "update_block.flow_head.conv2", 2, 3, out_f32=True)       # fp32 [..,4]
         lib.call("zt_raft_flow_step", st.coords1, st.delta, st.delta.shape[-1], h, w, st.F4, 4, HX.data_ptr() + st.es * 382, 384,
