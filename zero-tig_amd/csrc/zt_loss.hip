@@ -46,90 +46,120 @@ __constant__ int c_off_dy[12] = {1, 0, 1, 1, 2, 0, 2, 2, 1, 1, 2, 2};
 __constant__ int c_off_dx[12] = {0, 1, 1, -1, 0, 2, 1, -1, 2, -2, 2, -2};
 
 // Terms 0-3 (loss.py:46-49) and their direct gradient w.r.t. s2.  L2 is detached in all four.
+// A workgroup owns a 64 x 16 tile; the s2 and Y planes of the tile plus the +-2 halo that the 24 shifted differences of
+// SmoothLoss and the TV neighbours reach are staged ONCE in LDS (6 planes x 20 x 68 floats = 32 KB, coalesced loads); the
+// 150 neighbour reads per pixel then hit LDS instead of the texture path (the per-pixel global gathers made this kernel run
+// at 0.7 TB/s of its 100 MB).  Per-pixel arithmetic and its order are unchanged.
+constexpr int LS_TX = 64, LS_TY = 16, LS_HALO = 2, LS_PW = LS_TX + 2 * LS_HALO, LS_PH = LS_TY + 2 * LS_HALO;
+
 __global__ void __launch_bounds__(256) loss_s2_kernel(const float* __restrict__ L2, const float* __restrict__ s2,
                                                       const float* __restrict__ Y, const float* __restrict__ scal, int H,
-                                                      int W, float* __restrict__ ds2, float* __restrict__ partial) {
+                                                      int W, float* __restrict__ ds2, float* __restrict__ partial, int nrow4) {
   __shared__ float red[16 * 4];
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  __shared__ float sS[3][LS_PH][LS_PW];
+  __shared__ float sY[3][LS_PH][LS_PW];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int x0 = blockIdx.x * LS_TX, y0 = blockIdx.y * LS_TY;
   const size_t HW = (size_t)H * W;
+  for (int e = tid; e < 6 * LS_PH * LS_PW; e += 256) {
+    const int pl = e / (LS_PH * LS_PW), r = e - pl * (LS_PH * LS_PW);
+    const int ly = r / LS_PW, lx = r - ly * LS_PW;
+    const int gy = y0 + ly - LS_HALO, gx = x0 + lx - LS_HALO;
+    const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+    const float* src = pl < 3 ? s2 + pl * HW : Y + (pl - 3) * HW;
+    const float v = src[(size_t)gyc * W + gxc];                 // out-of-image slots are never used (bounds tests below)
+    if (pl < 3) sS[pl][ly][lx] = v;
+    else sY[pl - 3][ly][lx] = v;
+  }
+  __syncthreads();
   const float N3 = 3.f * (float)HW;
   float t[4] = {0.f, 0.f, 0.f, 0.f};
-  if (x < W && y < H) {
-    const size_t o = (size_t)y * W + x;
-    float g[3] = {0.f, 0.f, 0.f};
-    float sq[3], yq[3];
-    for (int c = 0; c < 3; ++c) {
-      sq[c] = s2[c * HW + o];
-      yq[c] = Y[c * HW + o];
-      float l = L2[c * HW + o], ef = scal[c], ratio = scal[3 + c];
-      float ceb = zt_clampf(powf(l * ef, ef) * ratio, 1e-9f, 1.f);
-      float d1 = sq[c] - ceb;
-      t[0] += d1 * d1 * (700.f / N3);
-      g[c] += d1 * (1400.f / N3);
-      float q = l / sq[c];
-      float nl = zt_clampf(q, 1e-9f, 0.8f), cal = zt_clampf(l * ef, 1e-9f, 1.f);
-      float d2 = nl - cal;
-      t[1] += d2 * d2 * (1000.f / N3);
-      if (q >= 1e-9f && q <= 0.8f) g[c] += d2 * (2000.f / N3) * (-q / sq[c]);
-      // total variation (loss.py:139-152), weight 1600
-      const float ch = 3200.f / ((float)(H - 1) * (float)W), cw = 3200.f / ((float)H * (float)(W - 1));
-      if (y + 1 < H) {
-        float d = s2[c * HW + o + W] - sq[c];
-        t[3] += d * d * ch;
-        g[c] -= 2.f * d * ch;
-      }
-      if (y >= 1) g[c] += 2.f * (sq[c] - s2[c * HW + o - W]) * ch;
-      if (x + 1 < W) {
-        float d = s2[c * HW + o + 1] - sq[c];
-        t[3] += d * d * cw;
-        g[c] -= 2.f * d * cw;
-      }
-      if (x >= 1) g[c] += 2.f * (sq[c] - s2[c * HW + o - 1]) * cw;
-    }
-    // bilateral smoothness (loss.py:173-311): 12 offsets, each counted twice, weight 5
-    for (int k = 0; k < 12; ++k) {
-      const int dy = c_off_dy[k], dx = c_off_dx[k];
-      const int adx = dx < 0 ? -dx : dx;
-      const float coef = 10.f / ((float)(H - dy) * (float)(W - adx));
-      // pair (q, q+d)
-      int yy = y + dy, xx = x + dx;
-      if (yy < H && xx >= 0 && xx < W) {
-        size_t oo = (size_t)yy * W + xx;
-        float e = 0.f, a = 0.f;
-        float sg[3];
-        for (int c = 0; c < 3; ++c) {
-          float dyv = yq[c] - Y[c * HW + oo];
-          e += dyv * dyv;
-          float ds = sq[c] - s2[c * HW + oo];
-          a += fabsf(ds);
-          sg[c] = ds > 0.f ? 1.f : (ds < 0.f ? -1.f : 0.f);
+  const int x = x0 + threadIdx.x, lx = threadIdx.x + LS_HALO;
+#pragma unroll 1
+  for (int j = 0; j < LS_TY / 4; ++j) {
+    const int y = y0 + threadIdx.y + 4 * j, ly = threadIdx.y + 4 * j + LS_HALO;
+    if (x < W && y < H) {
+      const size_t o = (size_t)y * W + x;
+      float g[3] = {0.f, 0.f, 0.f};
+      float sq[3], yq[3];
+      for (int c = 0; c < 3; ++c) {
+        sq[c] = sS[c][ly][lx];
+        yq[c] = sY[c][ly][lx];
+        float l = L2[c * HW + o], ef = scal[c], ratio = scal[3 + c];
+        float ceb = zt_clampf(powf(l * ef, ef) * ratio, 1e-9f, 1.f);
+        float d1 = sq[c] - ceb;
+        t[0] += d1 * d1 * (700.f / N3);
+        g[c] += d1 * (1400.f / N3);
+        float q = l / sq[c];
+        float nl = zt_clampf(q, 1e-9f, 0.8f), cal = zt_clampf(l * ef, 1e-9f, 1.f);
+        float d2 = nl - cal;
+        t[1] += d2 * d2 * (1000.f / N3);
+        if (q >= 1e-9f && q <= 0.8f) g[c] += d2 * (2000.f / N3) * (-q / sq[c]);
+        // total variation (loss.py:139-152), weight 1600
+        const float ch = 3200.f / ((float)(H - 1) * (float)W), cw = 3200.f / ((float)H * (float)(W - 1));
+        if (y + 1 < H) {
+          float d = sS[c][ly + 1][lx] - sq[c];
+          t[3] += d * d * ch;
+          g[c] -= 2.f * d * ch;
         }
-        float wgt = expf(e * -0.005f) * coef;
-        t[2] += wgt * a;
-        for (int c = 0; c < 3; ++c) g[c] += wgt * sg[c];
-      }
-      // pair (q-d, q): gradient only (the forward term belongs to pixel q-d)
-      yy = y - dy;
-      xx = x - dx;
-      if (yy >= 0 && xx >= 0 && xx < W) {
-        size_t oo = (size_t)yy * W + xx;
-        float e = 0.f;
-        float sg[3];
-        for (int c = 0; c < 3; ++c) {
-          float dyv = Y[c * HW + oo] - yq[c];
-          e += dyv * dyv;
-          float ds = sq[c] - s2[c * HW + oo];
-          sg[c] = ds > 0.f ? 1.f : (ds < 0.f ? -1.f : 0.f);
+        if (y >= 1) g[c] += 2.f * (sq[c] - sS[c][ly - 1][lx]) * ch;
+        if (x + 1 < W) {
+          float d = sS[c][ly][lx + 1] - sq[c];
+          t[3] += d * d * cw;
+          g[c] -= 2.f * d * cw;
         }
-        float wgt = expf(e * -0.005f) * coef;
-        for (int c = 0; c < 3; ++c) g[c] += wgt * sg[c];
+        if (x >= 1) g[c] += 2.f * (sq[c] - sS[c][ly][lx - 1]) * cw;
       }
+      // bilateral smoothness (loss.py:173-311): 12 offsets, each counted twice, weight 5
+      for (int k = 0; k < 12; ++k) {
+        const int dy = c_off_dy[k], dx = c_off_dx[k];
+        const int adx = dx < 0 ? -dx : dx;
+        const float coef = 10.f / ((float)(H - dy) * (float)(W - adx));
+        // pair (q, q+d)
+        int yy = y + dy, xx = x + dx;
+        if (yy < H && xx >= 0 && xx < W) {
+          float e = 0.f, a = 0.f;
+          float sg[3];
+          for (int c = 0; c < 3; ++c) {
+            float dyv = yq[c] - sY[c][ly + dy][lx + dx];
+            e += dyv * dyv;
+            float ds = sq[c] - sS[c][ly + dy][lx + dx];
+            a += fabsf(ds);
+            sg[c] = ds > 0.f ? 1.f : (ds < 0.f ? -1.f : 0.f);
+          }
+          float wgt = expf(e * -0.005f) * coef;
+          t[2] += wgt * a;
+          for (int c = 0; c < 3; ++c) g[c] += wgt * sg[c];
+        }
+        // pair (q-d, q): gradient only (the forward term belongs to pixel q-d)
+        yy = y - dy;
+        xx = x - dx;
+        if (yy >= 0 && xx >= 0 && xx < W) {
+          float e = 0.f;
+          float sg[3];
+          for (int c = 0; c < 3; ++c) {
+            float dyv = sY[c][ly - dy][lx - dx] - yq[c];
+            e += dyv * dyv;
+            float ds = sq[c] - sS[c][ly - dy][lx - dx];
+            sg[c] = ds > 0.f ? 1.f : (ds < 0.f ? -1.f : 0.f);
+          }
+          float wgt = expf(e * -0.005f) * coef;
+          for (int c = 0; c < 3; ++c) g[c] += wgt * sg[c];
+        }
+      }
+      for (int c = 0; c < 3; ++c) ds2[c * HW + o] = g[c];
     }
-    for (int c = 0; c < 3; ++c) ds2[c * HW + o] = g[c];
   }
   zt_block_sum<4>(t, red);
-  if (threadIdx.x == 0 && threadIdx.y == 0) {
-    float* p = partial + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4;
+  // the caller's partial buffer has one slot per 64 x 4 strip ([ceil(H/4)][ceil(W/64)][4]): this tile fills its first strip's slot
+  // and zeroes the other three
+  if (tid < 4 * (LS_TY / 4)) {
+    const int strip = blockIdx.y * (LS_TY / 4) + (tid >> 2);
+    if (strip < nrow4) partial[((size_t)strip * gridDim.x + blockIdx.x) * 4 + (tid & 3)] = 0.f;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float* p = partial + ((size_t)(blockIdx.y * (LS_TY / 4)) * gridDim.x + blockIdx.x) * 4;
     p[0] = t[0]; p[1] = t[1]; p[2] = t[2]; p[3] = t[3];
   }
 }
@@ -241,7 +271,8 @@ extern "C" int zt_loss_scalars_f32(const float* partial, int nblk, long long HW,
 extern "C" int zt_loss_s2_f32(const float* L2, const float* s2, const float* Y, const float* scal, int H, int W, float* ds2,
                               float* partial, hipStream_t stream) {
   ZT_REQUIRE(L2 && s2 && Y && scal && ds2 && partial && H > 2 && W > 2);
-  hipLaunchKernelGGL(loss_s2_kernel, dim3(zt_cdiv(W, 64), zt_cdiv(H, 4)), dim3(64, 4), 0, stream, L2, s2, Y, scal, H, W, ds2, partial);
+  hipLaunchKernelGGL(loss_s2_kernel, dim3(zt_cdiv(W, LS_TX), zt_cdiv(H, LS_TY)), dim3(64, 4), 0, stream, L2, s2, Y, scal, H, W, ds2, partial,
+                     zt_cdiv(H, 4));
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

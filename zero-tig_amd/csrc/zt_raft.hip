@@ -70,31 +70,34 @@ __global__ void __launch_bounds__(256) quantize_hist_kernel(const float* __restr
 }
 
 // torchvision 0.18.1 _scale_channel: step = floor(sum(nonzero_hist[:-1]) / 255); lut = floor((cumsum + step//2) / step),
-// shifted right by one, clamped; identity when step == 0.  One thread per channel (256 bins).
-__global__ void equalize_lut_kernel(const int* __restrict__ hist, int* __restrict__ lut, int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const int* h = hist + c * 256;
-  long long total = 0;
-  int last = -1;
-  for (int k = 0; k < 256; ++k) {
-    total += h[k];
-    if (h[k] != 0) last = k;
+// shifted right by one, clamped; identity when step == 0.  One 256-lane workgroup per channel: LDS scan of the 256 bins
+// (Hillis-Steele, 8 rounds), one integer division per lane.  Counts are pixel counts (< 2^31): 32-bit arithmetic is exact.
+__global__ void __launch_bounds__(256) equalize_lut_kernel(const int* __restrict__ hist, int* __restrict__ lut, int C) {
+  __shared__ int cum[2][256];
+  __shared__ int lastk[256];
+  const int c = blockIdx.x, k = threadIdx.x;
+  const int hk = hist[c * 256 + k];
+  cum[0][k] = hk;
+  lastk[k] = hk != 0 ? k : -1;
+  __syncthreads();
+  int cur = 0;
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = cum[cur][k] + (k >= off ? cum[cur][k - off] : 0);
+    const int m = max(lastk[k], k >= off ? lastk[k - off] : -1);
+    __syncthreads();
+    cum[cur ^ 1][k] = v;
+    lastk[k] = m;
+    __syncthreads();
+    cur ^= 1;
   }
-  long long step = last >= 0 ? (total - h[last]) / 255 : 0;
-  int* l = lut + c * 256;
-  if (step == 0) {
-    for (int k = 0; k < 256; ++k) l[k] = k;
-    return;
+  const int total = cum[cur][255], last = lastk[255];                 // inclusive scans: sum / running max of non-empty bins
+  const int step = last >= 0 ? (total - hist[c * 256 + last]) / 255 : 0;
+  int v = k;
+  if (step != 0) {
+    v = k == 0 ? 0 : (cum[cur][k - 1] + step / 2) / step;          // pad-left by one: lut[k] = value computed for bin k-1
+    v = v > 255 ? 255 : v;
   }
-  long long cum = 0, prev = 0;
-  for (int k = 0; k < 256; ++k) {
-    long long v = prev;                    // pad-left by one: lut[k] = value computed for bin k-1
-    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    l[k] = (int)v;
-    cum += h[k];
-    prev = (cum + step / 2) / step;
-  }
+  lut[c * 256 + k] = v;
 }
 
 // RAFT.forward head (raft.py:80-83, 132-138): centred replicate pad to /8 and 2*(x/255)-1, both frames into one NHWC4
@@ -316,7 +319,7 @@ extern "C" int zt_equalize_prepare_u8(const float* src, unsigned char* q, int* h
   int nb = zt_cdiv(hw, 256 * 8);
   nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
   hipLaunchKernelGGL(quantize_hist_kernel, dim3(nb, C), dim3(256), 0, stream, src, q, hist, hw);
-  hipLaunchKernelGGL(equalize_lut_kernel, dim3(1), dim3(64), 0, stream, (const int*)hist, lut, C);
+  hipLaunchKernelGGL(equalize_lut_kernel, dim3(C), dim3(256), 0, stream, (const int*)hist, lut, C);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
