@@ -417,6 +417,7 @@ constexpr int HCK = 32;                 // channel granularity of a two-part (sp
 template <int KH, int KW, int S, int NT, int MT, bool ALL, int CH2, int PD>
 __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
   static_assert(ALL || PD == 1, "per-row weight groups are staged inside the chunk");
+  if (a.dbg & 8) return;                                        // tuning ablation (tools/bench_small.py): launch cost only
   constexpr int KCH = 32 * CH2, KCHP = CH2 == 2 ? 80 : 48, CPP = 4 * CH2;      // channels / LDS pitch / 16-byte chunks per pixel
   constexpr int TWm = 16 * MT;
   constexpr int IR = (TH - 1) * S + KH, IC = (TWm - 1) * S + KW;
@@ -447,30 +448,58 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
   // issued before this chunk's MFMAs, so one global latency is exposed per launch rather than several per chunk.
   constexpr int NWS = (TG * NT * 16 * CPP + 255) / 256;
   constexpr int NXS = (IR * IC * CPP + 255) / 256;
+  static_assert(256 % CPP == 0, "a thread's channel octet is the same for all of its staging slots");
   uint4 wv[PD][NWS], xv[PD][NXS];
+  // Chunk-invariant slot geometry, computed ONCE: the per-chunk staging code is then a handful of adds per 16-byte slot.  (With
+  // the index arithmetic inside the chunk loop these kernels issued ~1200 scalar + vector ALU instructions per 20 MFMAs and
+  // were issue-bound on it: every small-map RAFT layer took 11-16 us whatever its FLOP count.)
+  const int q8 = (tid % CPP) * 8;                               // this thread's channel octet within a chunk (all slots)
+  int x_src1[NXS], x_src2[NXS], x_lds[NXS];
+  unsigned x_in[NXS];
+#pragma unroll
+  for (int i = 0; i < NXS; ++i) {
+    const int e = tid + i * 256, p = e / CPP;
+    const int gy = gy0 + p / IC, gx = gx0 + p % IC;
+    const int gyc = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+    const int pix = (n * a.H + gyc) * a.W + gxc;
+    x_src1[i] = pix * a.ldx + q8;
+    x_src2[i] = pix * a.ldx2 + q8;
+    x_lds[i] = e < IR * IC * CPP ? p * KCHP + q8 : -1;
+    x_in[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ~0u : 0u;
+  }
+  int w_src[NWS], w_lds[NWS];
+  unsigned w_ok[NWS];
+#pragma unroll
+  for (int i = 0; i < NWS; ++i) {
+    const int e = tid + i * 256, r = e / CPP;
+    const int co = r % (NT * 16), tl = r / (NT * 16);
+    const int tlc = tl < TG ? tl : TG - 1;                      // padding slots (never written) stay inside the weight array
+    const int cor = co0 + co < a.CoutP ? co0 + co : a.CoutP - 1;
+    w_src[i] = (tlc * a.CoutP + cor) * a.ldk + q8;
+    w_lds[i] = e < TG * NT * 16 * CPP ? (tl * NT * 16 + co) * KCHP + q8 : -1;
+    w_ok[i] = co0 + co < a.CoutP ? ~0u : 0u;
+  }
+  const int w_grp_stride = TG * a.CoutP * a.ldk;
   auto load_w = [&](auto sl, int c0, int grp) {
     constexpr int d = decltype(sl)::value;
+    const int add = c0 + grp * w_grp_stride;
+    const bool ragged = c0 + KCH > a.ldk;                       // uniform: only a ragged last chunk needs the channel clamp
 #pragma unroll
     for (int i = 0; i < NWS; ++i) {
-      const int e = tid + i * 256;
-      const int q = e % CPP, r = e / CPP;
-      const int co = r % (NT * 16), tl = r / (NT * 16);
-      int tap = grp * TG + tl;
-      tap = tap < KH * KW ? tap : KH * KW - 1;
-      const int c = c0 + q * 8;
-      const int cor = co0 + co < a.CoutP ? co0 + co : a.CoutP - 1;
-      wv[d][i] = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.CoutP + cor) * a.ldk + (c < a.ldk ? c : 0));
+      int off = w_src[i] + add;
+      if (ragged) off = c0 + q8 < a.ldk ? off : off - (c0 + q8);
+      wv[d][i] = *reinterpret_cast<const uint4*>(a.w + (unsigned)off);
     }
   };
   auto write_w = [&](auto sl, int c0) {
     constexpr int d = decltype(sl)::value;
+    const unsigned cok = (c0 + q8 < a.ldk && c0 < a.Cin) ? ~0u : 0u;   // beyond the weight row / a padding chunk: zeros
 #pragma unroll
     for (int i = 0; i < NWS; ++i) {
-      const int e = tid + i * 256;
-      const int q = e % CPP, r = e / CPP;
-      const int co = r % (NT * 16), tl = r / (NT * 16);
-      const bool ok = c0 + q * 8 < a.ldk && co0 + co < a.CoutP;
-      if (e < TG * NT * 16 * CPP) *reinterpret_cast<uint4*>(ws + (tl * NT * 16 + co) * KCHP + q * 8) = ok ? wv[d][i] : make_uint4(0u, 0u, 0u, 0u);
+      const unsigned m = w_ok[i] & cok;
+      uint4 v = wv[d][i];
+      v.x &= m; v.y &= m; v.z &= m; v.w &= m;
+      if (w_lds[i] >= 0) *reinterpret_cast<uint4*>(ws + w_lds[i]) = v;
     }
   };
   auto load_x = [&](auto sl, int c0) {
@@ -479,15 +508,12 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
     const zt_bf16* src = second ? a.x2 : a.x;
     const int ld = second ? a.ldx2 : a.ldx;
     const int cbase = second ? c0 - a.csplit : c0;
+    const bool ragged = cbase + KCH > ld;
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
-      const int e = tid + i * 256;
-      const int p = e / CPP, q = e % CPP;
-      int gy = gy0 + p / IC, gx = gx0 + p % IC;
-      gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
-      gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-      const int c = cbase + q * 8;
-      xv[d][i] = *reinterpret_cast<const uint4*>(src + (size_t)((n * a.H + gy) * a.W + gx) * ld + (c < ld ? c : 0));
+      int off = (second ? x_src2[i] : x_src1[i]) + cbase;
+      if (ragged) off = cbase + q8 < ld ? off : off - (cbase + q8);
+      xv[d][i] = *reinterpret_cast<const uint4*>(src + (unsigned)off);
     }
   };
   auto write_x = [&](auto sl, int c0) {
@@ -495,78 +521,99 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
     const bool second = a.x2 != nullptr && c0 >= a.csplit;
     const int cbase = second ? c0 - a.csplit : c0;
     const int climit = second ? a.Cin - a.csplit : (a.x2 ? a.csplit : a.Cin);
+    const int nv = climit - (cbase + q8);                         // valid channels of this thread's octet (ragged tail / beyond the input)
+    const unsigned m0 = nv >= 2 ? ~0u : (nv == 1 ? 0xFFFFu : 0u), m1 = nv >= 4 ? ~0u : (nv == 3 ? 0xFFFFu : 0u);
+    const unsigned m2 = nv >= 6 ? ~0u : (nv == 5 ? 0xFFFFu : 0u), m3 = nv >= 8 ? ~0u : (nv == 7 ? 0xFFFFu : 0u);
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
-      const int e = tid + i * 256;
-      const int p = e / CPP, q = e % CPP;
-      const int gy = gy0 + p / IC, gx = gx0 + p % IC;
-      const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      const int nv = climit - (cbase + q * 8);                  // valid channels of this 8-chunk (ragged tail / beyond the input)
-      const unsigned m0 = nv >= 2 ? ~0u : (nv == 1 ? 0xFFFFu : 0u), m1 = nv >= 4 ? ~0u : (nv == 3 ? 0xFFFFu : 0u);
-      const unsigned m2 = nv >= 6 ? ~0u : (nv == 5 ? 0xFFFFu : 0u), m3 = nv >= 8 ? ~0u : (nv == 7 ? 0xFFFFu : 0u);
       uint4 v = xv[d][i];
-      v.x = in ? (v.x & m0) : 0u;
-      v.y = in ? (v.y & m1) : 0u;
-      v.z = in ? (v.z & m2) : 0u;
-      v.w = in ? (v.w & m3) : 0u;
-      if (e < IR * IC * CPP) *reinterpret_cast<uint4*>(xs + p * KCHP + q * 8) = v;
+      v.x &= x_in[i] & m0;
+      v.y &= x_in[i] & m1;
+      v.z &= x_in[i] & m2;
+      v.w &= x_in[i] & m3;
+      if (x_lds[i] >= 0) *reinterpret_cast<uint4*>(xs + x_lds[i]) = v;
     }
   };
 
-  zt_static_for<0, PD>([&](auto sl) {
-    constexpr int d = decltype(sl)::value;
-    if (d * KCH < a.Cin) {
-      load_x(sl, d * KCH);
-      load_w(sl, d * KCH, 0);
-    }
-  });
-  for (int cb = 0; cb < a.Cin; cb += PD * KCH) {
+  // Chunk loop.  Every load is issued UNCONDITIONALLY (chunk index clamped to the last one; the channel range is padded to a
+  // multiple of PD chunks whose padding chunks are staged as zeros): with `if (more)` around the prefetch the compiler lost
+  // count of the outstanding loads and put s_waitcnt vmcnt(0) in front of every LDS write, i.e. one full memory latency per
+  // chunk however deep the prefetch (1.6-2.6 us per chunk on the 45 x 80 maps; measured with tools/bench_small.py).
+  const int nch = (a.dbg & 4) ? 0 : (a.Cin + KCH - 1) / KCH;     // dbg 4: prologue + epilogue only
+  const int last_c0 = (nch - 1) * KCH;
+  if (nch > 0) {
     zt_static_for<0, PD>([&](auto sl) {
       constexpr int d = decltype(sl)::value;
-      const int c0 = cb + d * KCH;
-      if (c0 < a.Cin) {                                           // uniform
-        __syncthreads();
-        write_x(sl, c0);
-        write_w(sl, c0);
-        __syncthreads();
-        const int cn = c0 + PD * KCH;
-        const bool more = cn < a.Cin;
-        if (more) load_x(sl, cn);
-        if (ALL && more) load_w(sl, cn, 0);                       // single tap group: its weights are prefetched as well
+      const int c0 = d * KCH <= last_c0 ? d * KCH : last_c0;
+      load_x(sl, c0);
+      load_w(sl, c0, 0);
+    });
+  }
+  // fragment reads run LA (tap, channel-half) steps ahead of the MFMAs that consume them (LDS latency ~100+ clocks against
+  // MT*NT*16 clocks of MFMA per step; the compiler's own schedule waited for each step's reads right before its MFMAs)
+  constexpr int NSTEP = TG * CH2;
+  constexpr int LA = NSTEP > 2 ? 2 : 1;
+  const zt_bf16* xfrag = xs + ((wave * S) * IC + l15 * S) * KCHP + 8 * l4;
+  const zt_bf16* wfrag = ws + l15 * KCHP + 8 * l4;
+  const int ngroups = (nch + PD - 1) / PD;
+  const int nrep = (a.dbg & 16) ? 4 : 1;                          // ablation: walk the K range four times (cold-start vs steady-state cost)
 #pragma unroll 1
-        for (int grp = 0; grp < NG; ++grp) {
-          if (grp > 0) {                                          // per-kernel-row weight groups (7x7): staged inside the chunk
-            __syncthreads();
-            load_w(sl, c0, grp);
-            write_w(sl, c0);
-            __syncthreads();
-          }
-#pragma unroll
-          for (int tl = 0; tl < TG; ++tl) {
-            const int ky = ALL ? tl / KW : grp, kx = ALL ? tl % KW : tl;
-#pragma unroll
-            for (int kc = 0; kc < CH2; ++kc) {
-              zt_s16x8 av[MT], bv[NT];
-#pragma unroll
-              for (int m = 0; m < MT; ++m)
-                av[m] = *reinterpret_cast<const zt_s16x8*>(xs + ((wave * S + ky) * IC + (m * 16 + l15) * S + kx) * KCHP + kc * 32 + 8 * l4);
-#pragma unroll
-              for (int q = 0; q < NT; ++q)
-                bv[q] = *reinterpret_cast<const zt_s16x8*>(ws + (tl * NT * 16 + q * 16 + l15) * KCHP + kc * 32 + 8 * l4);
-#pragma unroll
-              for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(av[m], bv[q], acc[m][q]);
-            }
-          }
+  for (int rep = 0; rep < nrep; ++rep)
+#pragma unroll 1
+  for (int g = 0; g < ngroups; ++g) {
+    zt_static_for<0, PD>([&](auto sl) {
+      constexpr int d = decltype(sl)::value;
+      const int c0 = (g * PD + d) * KCH;                          // >= Cin: a padding chunk (staged as zeros)
+      __syncthreads();
+      write_x(sl, c0);
+      write_w(sl, c0);
+      __syncthreads();
+      const int cn = c0 + PD * KCH <= last_c0 ? c0 + PD * KCH : last_c0;
+      load_x(sl, cn);
+      if (ALL) load_w(sl, cn, 0);                                 // single tap group: its weights are prefetched as well
+#pragma unroll 1
+      for (int grp = 0; grp < NG; ++grp) {
+        if (grp > 0) {                                            // per-kernel-row weight groups (7x7): staged inside the chunk
+          __syncthreads();
+          load_w(sl, c0, grp);
+          write_w(sl, c0);
+          __syncthreads();
         }
-        if (!ALL && more) load_w(sl, cn, 0);
+        zt_s16x8 fa[LA + 1][MT], fb[LA + 1][NT];
+        auto loadf = [&](auto bc, auto sc) {
+          constexpr int bi = decltype(bc)::value, step = decltype(sc)::value;
+          constexpr int tl = step / CH2, kc = step % CH2;
+          const int ky = ALL ? tl / KW : grp, kx = ALL ? tl % KW : tl;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            fa[bi][m] = *reinterpret_cast<const zt_s16x8*>(xfrag + (ky * IC + m * 16 * S + kx) * KCHP + kc * 32);
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+            fb[bi][q] = *reinterpret_cast<const zt_s16x8*>(wfrag + (tl * NT * 16 + q * 16) * KCHP + kc * 32);
+        };
+        zt_static_for<0, LA>([&](auto sc) { loadf(ZtIdx<decltype(sc)::value % (LA + 1)>{}, sc); });
+        zt_static_for<0, NSTEP>([&](auto sc) {
+          constexpr int step = decltype(sc)::value;
+          constexpr int cur = step % (LA + 1);
+          if constexpr (step + LA < NSTEP) loadf(ZtIdx<(step + LA) % (LA + 1)>{}, ZtIdx<step + LA>{});
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc[m][q] = zt_mfma_bf16(fa[cur][m], fb[cur][q], acc[m][q]);
+          __builtin_amdgcn_sched_barrier(0);
+        });
       }
+      if (!ALL) load_w(sl, cn, 0);
     });
   }
 
   const int oy = oy0 + wave;
   if (oy >= a.Ho) return;
+  if (a.dbg & 2) {                                              // ablation: no epilogue (accumulators kept live)
+    if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[MT - 1][NT - 1][3];
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < NT; ++q) {
     const int co = co0 + q * 16 + l15;
@@ -613,7 +660,7 @@ int launch_conv_h(const ConvArgsH& a, int NT, unsigned gx, hipStream_t stream) {
   constexpr int IRc = (TH - 1) * S + KH, ICc = (16 * MT - 1) * S + KW;
   // 64-channel chunks where every chunk is full: Cin (and the split point of a two-part input) multiples of 64
   const bool wide = a.Cin % 64 == 0 && (!a.x2 || a.csplit % 64 == 0);
-  // latency-bound launches (about two workgroups per CU or fewer, several channel chunks): three chunks of loads in flight
+  // latency-bound launches (about two workgroups per CU or fewer, several channel chunks): two chunks of loads in flight
   const bool deep = MT == 1 && (long long)grid.x * grid.y <= 1024 && a.Cin > 64;
 #define ZT_CH(nt)                                                                                             \
   {                                                                                                           \
@@ -624,7 +671,7 @@ int launch_conv_h(const ConvArgsH& a, int NT, unsigned gx, hipStream_t stream) {
       if (wide) {                                                                                             \
         if constexpr (MT == 1) {                                                                              \
           if (deep) {                                                                                         \
-            hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all2, 2, 3>), grid, block, 0, stream, a); \
+            hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all2, 2, 2>), grid, block, 0, stream, a); \
             break;                                                                                            \
           }                                                                                                   \
         }                                                                                                     \
@@ -634,7 +681,7 @@ int launch_conv_h(const ConvArgsH& a, int NT, unsigned gx, hipStream_t stream) {
     }                                                                                                         \
     if constexpr (MT == 1 && all1) {                                                                          \
       if (deep) {                                                                                             \
-        hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all1, 1, 3>), grid, block, 0, stream, a); \
+        hipLaunchKernelGGL((conv_mfma_bf16_kernel<KH, KW, S, nt, MT, all1, 1, 2>), grid, block, 0, stream, a); \
         break;                                                                                                \
       }                                                                                                       \
     }                                                                                                         \
@@ -1736,10 +1783,13 @@ static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, 
   a.Cout = Cout; a.CoutP = CoutP; a.ldk = ldk; a.ldy = ldy; a.ldaux = ldaux;
   a.padH = padH; a.padW = padW; a.act = act; a.epi = epi; a.out_mode = out_mode; a.alpha = alpha;
   a.y2 = (zt_bf16*)y2; a.ldy2 = ldy2; a.esplit = esplit;
-  a.dbg = variant >= 32 ? (variant - 32) : (variant >= 16 ? (variant - 16) : 0);   // tuning ablations, see tools/bench_conv.py
+  a.dbg = variant >= 64 ? (variant - 64) : (variant >= 32 ? (variant - 32) : (variant >= 16 ? (variant - 16) : 0));   // tuning ablations, see tools/bench_conv.py / bench_small.py
+  if (variant >= 64) variant = 2;
   if (variant >= 32) variant = 3;
   if (variant >= 16) variant = 1;
   ZT_REQUIRE(a.Ho > 0 && a.Wo > 0);
+  // 32-bit element offsets in the staging code
+  ZT_REQUIRE((long long)N * H * W * (ldx > ldx2 ? ldx : ldx2) < 0x7FFFFFFFll && (long long)KH * KW * CoutP * ldk < 0x7FFFFFFFll);
   a.tilesY = zt_cdiv(a.Ho, TH);
   int c16 = (Cout + 15) / 16;
   int NT = c16 >= 4 ? ((c16 % 4 == 0) ? 4 : (c16 % 3 == 0 ? 3 : 4)) : c16;
@@ -1748,6 +1798,11 @@ static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, 
   long long wgs = (long long)zt_cdiv(a.Wo, 32) * a.tilesY * N * zt_cdiv(c16, NT);
   if (wgs < 512 || stride == 2) MT = 1;
   if (MT == 1 && NT == 4 && (long long)zt_cdiv(a.Wo, 16) * a.tilesY * N * zt_cdiv(c16, NT) < 512 && c16 % 2 == 0) NT = 2;
+  if (wgs < 512 && stride == 1) {                               // tuning hooks for the small-map tile shape (tools/bench_small.py)
+    static const int fmt = getenv("ZT_TILED_MT") ? atoi(getenv("ZT_TILED_MT")) : 0, fnt = getenv("ZT_TILED_NT") ? atoi(getenv("ZT_TILED_NT")) : 0;
+    if (fmt == 1 || fmt == 2) MT = fmt;
+    if (fnt >= 1 && fnt <= 4 && c16 % fnt == 0) NT = fnt;
+  }
   // full-resolution stride-1 layers of the enhancement nets: persistent weight-stationary kernel
   const bool ws_ok = N == 1 && stride == 1 && KH == KW && (KH == 1 || KH == 3) && padH == KH / 2 && padW == KW / 2 && Cin <= 64 && !x2;
   ZT_REQUIRE(variant != 1 || ws_ok);
