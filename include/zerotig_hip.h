@@ -214,8 +214,18 @@ int zt_conv2d_nhwc_bf16_ex(const void* x, const void* x2, int csplit, int ldx, i
                            int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout, int KH, int KW, int stride,
                            int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi, void* y2, int ldy2, int esplit,
                            zt_stream_t stream);
+/* Enhancer block head (model.py:60-62): y = conv3x3(x) + bias (stride 1, pad 1, N == 1, bf16 nhwc) AND the train-mode
+ * BatchNorm statistics of y in the same pass: stats [stats_blocks = 512][2][Cout] per-workgroup partial (sum, sum of squares) of
+ * the stored values, zero-filled beyond the launch's workgroups -- feed to zt_norm_finalize_f32(partial = stats, nblk = 512).
+ * The 64 -> 64 full-resolution layer accumulates them in the register-stationary kernel's store phase; any other geometry runs
+ * the convolution followed by the statistics kernel (same output contract). */
+int zt_conv3x3_bn_stats_bf16(const void* x, int ldx, int H, int W, int Cin, const void* w, int CoutP, int ldk, const float* bias,
+                             void* y, int ldy, int Cout, float* stats, int stats_blocks, zt_stream_t stream);
+/* relu_mask (optional, thin-input 3x3 layer with 64 couts): dz is taken as dz * [relu_mask > 0], i.e. the backward of the ReLU
+ * that follows the layer (model.py:55-56) is folded into the staging of dz instead of a separate masking pass */
 int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout, int KH, int KW,
-                              float* slab, size_t slab_bytes, float* grad_w, float* grad_b, int accumulate, zt_stream_t stream);
+                              float* slab, size_t slab_bytes, float* grad_w, float* grad_b, int accumulate, const void* relu_mask,
+                              int ldmask, zt_stream_t stream);
 int zt_repack_conv_weight_bf16(const float* src, void* dst, int Cout, int Cin, int KH, int KW, int CoutP, int ldk, int co_off,
                                int transpose_flip, zt_stream_t stream);
 

@@ -506,6 +506,14 @@ def test_conv_wgrad_bf16(backend, case):
         ops.conv2d_wgrad_bf16(CV(_nhwc_bf16(x, ldx).to(dev), 0, Cin), CV(_nhwc_bf16(dz, lddz).to(dev), 0, Cout), Cout, K, K, gw, grad_b=gb)
         assert maxerr(gw, w.grad) < 2e-3 * float(w.grad.abs().max()), maxerr(gw, w.grad)
         assert maxerr(gb, dz.sum(dim=(0, 2, 3))) < 1e-3 * (H * W) ** 0.5
+        if K == 3 and Cin <= 16 and Cout == 64:      # folded ReLU mask == the same kernel on a pre-masked dz, bit for bit
+            act = torch.relu(torch.randn(1, Cout, H, W, generator=g)).bfloat16().float()
+            xd = CV(_nhwc_bf16(x, ldx).to(dev), 0, Cin)
+            g1, b1 = torch.zeros((Cout, Cin, K, K), device=dev), torch.zeros((Cout,), device=dev)
+            g2, b2 = torch.zeros_like(g1), torch.zeros_like(b1)
+            ops.conv2d_wgrad_bf16(xd, CV(_nhwc_bf16(dz, lddz).to(dev), 0, Cout), Cout, K, K, g1, grad_b=b1, relu_mask=_nhwc_bf16(act, 64).to(dev))
+            ops.conv2d_wgrad_bf16(xd, CV(_nhwc_bf16(dz * (act > 0), lddz).to(dev), 0, Cout), Cout, K, K, g2, grad_b=b2)
+            assert torch.equal(g1, g2) and torch.equal(b1, b2) and float(g1.abs().max()) > 0
 
 
 BF16_GEO = [
@@ -569,3 +577,32 @@ def test_conv_bf16_split_input_and_row_offset(backend):
     wd1 = ops.repack_weight_bf16(w1.to(dev))
     y1 = ops.conv2d_bf16(CV(_nhwc_bf16(xa, 32).to(dev)), wd1, b1[32:].contiguous().to(dev), 32, 1, 1, (0, 0), "relu", w_roff=32, out_f32=True)
     assert maxerr(y1.cpu().permute(0, 3, 1, 2), ref1) < 1e-3
+
+
+@pytest.mark.parametrize("force_fused", [True, False], ids=["fused", "fallback"])
+def test_conv3x3_bn_stats_bf16(backend, force_fused, monkeypatch):
+    """Enhancer block head (model.py:60-62): conv3x3 64->64 with the train-mode BatchNorm statistics accumulated in the same kernel
+    (register-stationary store phase) == the convolution followed by the stand-alone statistics pass; 19 x 37: ragged tiles."""
+    import torch.nn.functional as F
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    monkeypatch.setenv("ZT_STATS_FUSE_MIN_TILES", "1" if force_fused else "1000000000")
+    g = torch.Generator().manual_seed(11)
+    H, W = 19, 37
+    x = torch.randn(1, 64, H, W, generator=g).bfloat16().float()
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(64, generator=g) * 0.1
+    xd = _nhwc_bf16(x, 64).to(dev)
+    wd = ops.repack_weight_bf16(w.to(dev))
+    y, part = ops.conv3x3_bn_stats_bf16(CV(xd, 0, 64), wd, b.to(dev), 64)
+    ref = F.conv2d(x, w.bfloat16().float(), b, padding=1)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert float(((got - ref).abs() - ref.abs() * 2 ** -8).max()) < 2e-3
+    # the statistics are those of the STORED (bf16-rounded) values, summed in fp32
+    s = part.cpu().double().sum(dim=(0, 1))
+    assert float((s[0] - got.double().sum(dim=(0, 2, 3))).abs().max()) < 1e-3 * H * W ** 0.5
+    assert float((s[1] - (got.double() ** 2).sum(dim=(0, 2, 3))).abs().max()) < 1e-3 * H * W
+    sc, sh, mean, rstd = ops.norm_finalize(part, 1, 64, H * W, 0)
+    assert maxerr(mean, got.mean(dim=(0, 2, 3)).view(1, 64)) < 1e-5
+    assert maxerr(rstd, 1.0 / torch.sqrt(got.double().var(dim=(0, 2, 3), unbiased=False) + 1e-5).view(1, 64)) < 1e-4

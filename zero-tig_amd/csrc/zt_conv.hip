@@ -403,6 +403,7 @@ struct ConvArgsH {
   int tilesX, tilesY;
   zt_bf16* y2;                 // epi 4: second destination (r * h), channels [esplit, Cout) go there
   int ldy2, esplit;
+  float* stats;                // conv_rs STATS: per-workgroup (sum, sum of squares) of the stored outputs, [grid][2][Cout]
 };
 
 constexpr int HCK = 32;                 // channel granularity of a two-part (split) input
@@ -1051,8 +1052,14 @@ __device__ __forceinline__ zt_f32x4 zt_mfma_bf16_k16(zt_s16x4 a, zt_s16x4 b, zt_
 // RT = tile rows = waves per workgroup: 8 (one workgroup per CU, double-buffered staging) or 4 (two independent workgroups per
 // CU, single staging buffer: one workgroup's epilogue / barrier / DMA issue overlaps the other's MFMA loop; not for EPI, whose
 // aux operand needs the second staging buffer)
-template <int NQ, int NM, bool COSPLIT, int C32, int C16, bool EPI, int RT>
+// STATS: the train-mode BatchNorm that follows the layer (model.py:62) needs the per-channel sum and sum of squares of the output
+// over all pixels: they are accumulated from the staged (bf16-rounded, i.e. exactly the stored) values in the store phase --
+// per-thread over its chunks, butterfly over the 8 lanes of a wave that own the same channel octet, then into a per-wave LDS
+// table owned lane by lane (no atomics: fixed summation order, bit-reproducible) -- and written once per workgroup at the end;
+// zt_norm_finalize_f32 reduces the [grid][2][Cout] partials.  Replaces a separate 265 MB read pass per Enhancer block.
+template <int NQ, int NM, bool COSPLIT, int C32, int C16, bool EPI, int RT, bool STATS = false>
 __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(ConvArgsH a, int ntiles) {
+  static_assert(!STATS || (!EPI && RT == 4), "statistics are fused into the plain 4-row forward variant");
   constexpr int RTH = RT, NTHR = 64 * RT, NST = RT == 8 ? 2 : 1;
   // fused aux operand (activation mask / residual): the 8-row form DMAs its tile into the idle staging buffer (AUXL); the 4-row
   // form has no second staging buffer and reads it in accumulator layout (8 bytes per lane and 16x16 block) half a loop ahead
@@ -1075,10 +1082,14 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
   __shared__ __attribute__((aligned(16))) zt_bf16 xs[2][IR * IC * PE];
   __shared__ __attribute__((aligned(16))) zt_bf16 st[NST][RTH * TW * CW];
   __shared__ float bias_s[CW];
+  __shared__ __attribute__((aligned(16))) float stat_s[STATS ? RT * 2 * CW : 4];      // [wave][octet][sum 8 | sumsq 8]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int rp = wave >> 1, sel = wave & 1;
+  if constexpr (STATS) {
+    for (int e = tid; e < RT * 2 * CW; e += NTHR) stat_s[e] = 0.f;
+  }
   const int q0 = COSPLIT ? sel * NQ : 0, m0 = COSPLIT ? 0 : sel;
 
   if (tid < CW) bias_s[tid] = a.bias ? a.bias[tid] : 0.f;
@@ -1254,6 +1265,11 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
       else zt_wait_vmcnt0();
     }
     uint4 v[NOUT], ux[AUXS ? NOUT : 1];
+    float ssum[STATS ? 8 : 1], ssq[STATS ? 8 : 1];
+    if constexpr (STATS) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ssum[c] = ssq[c] = 0.f;
+    }
     if constexpr (AUXS) {                                       // aux chunks straight from global (16 bytes per lane), all in flight
 #pragma unroll
       for (int i = 0; i < NOUT; ++i) {
@@ -1301,6 +1317,39 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
         o = v[i];
       }
       if (oy < a.Ho && ox < a.Wo) *reinterpret_cast<uint4*>((zt_bf16*)a.y + (unsigned)((oy * a.Wo + ox) * a.ldy + ch * 8)) = o;
+      if constexpr (STATS) {
+        if (oy < a.Ho && ox < a.Wo) {
+          const unsigned ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float f0 = zt_u2f(ow[j] << 16), f1 = zt_u2f(ow[j] & 0xFFFF0000u);
+            ssum[2 * j] += f0;
+            ssum[2 * j + 1] += f1;
+            ssq[2 * j] += f0 * f0;
+            ssq[2 * j + 1] += f1 * f1;
+          }
+        }
+      }
+    }
+    if constexpr (STATS) {
+      // chunk e = tid + NTHR i has channel octet tid % 8 for every i: lanes l, l^8, l^16, l^32 of a wave share it
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        ssum[c] += __shfl_xor(ssum[c], 8);
+        ssq[c] += __shfl_xor(ssq[c], 8);
+        ssum[c] += __shfl_xor(ssum[c], 16);
+        ssq[c] += __shfl_xor(ssq[c], 16);
+        ssum[c] += __shfl_xor(ssum[c], 32);
+        ssq[c] += __shfl_xor(ssq[c], 32);
+      }
+      if (lane < 8) {                                           // lane owns octet `lane` of this wave's table
+        float* t = stat_s + (wave * CH8 + lane) * 16;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          t[c] += ssum[c];
+          t[8 + c] += ssq[c];
+        }
+      }
     }
   };
 
@@ -1440,6 +1489,16 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
     if (AUXL) glds_aux(n_my - 1, n_my & 1);
     store_tile(n_my - 1);
   }
+  if constexpr (STATS) {
+    __syncthreads();
+    if (tid < 2 * CW) {                                         // stats[block][0: sum | 1: sum of squares][channel]
+      const int which = tid / CW, c = tid % CW;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < RT; ++w) t += stat_s[(w * CH8 + (c >> 3)) * 16 + which * 8 + (c & 7)];
+      a.stats[(size_t)blockIdx.x * 2 * CW + tid] = t;
+    }
+  }
 }
 
 int launch_conv_rs(ConvArgsH& a, hipStream_t stream) {
@@ -1452,6 +1511,14 @@ int launch_conv_rs(ConvArgsH& a, hipStream_t stream) {
   const int maxg = rt == 4 ? 512 : 256;
   dim3 grid(ntiles < maxg ? ntiles : maxg), block(64 * rt);
   const int kc = a.Cin <= 16 ? 0 : (a.Cin > 48 ? 2 : 1);       // 0: one K=16 chunk, 1: 32 + 16, 2: 32 + 32
+  if (a.stats) {                                                // fused BatchNorm statistics: the 64 -> 64 forward layer, 4-row tiles
+    if (!(a.Cout == 64 && kc == 2 && !a.epi)) return ZT_EINVAL;
+    a.tilesY = zt_cdiv(a.Ho, 4);
+    const int nt4 = a.tilesX * a.tilesY;
+    dim3 g4(nt4 < 512 ? nt4 : 512);
+    hipLaunchKernelGGL((conv_rs_bf16_kernel<2, 2, true, 2, 0, false, 4, true>), g4, dim3(256), 0, stream, a, nt4);
+    return 0;
+  }
 #define ZT_RS(nq, nm, cs, c32, c16)                                                                                            \
   {                                                                                                                            \
     if (a.epi && rt == 4) {                                                                                                    \
@@ -1480,12 +1547,14 @@ struct WgradArgsH {
   float* slab;
   int H, W, Cin, ldx, Cout, lddz;
   int tilesX, ntiles;
+  const zt_bf16* mask;         // MASK: dz is taken as dz * [mask > 0] (the ReLU that follows the layer, folded in)
+  int ldmask;
 };
 
 constexpr int HTW = 32;                 // tile = HTH rows x 32 pixels; HTH = 2 * NW (4 or 8): 8-wave workgroups keep twice the bytes in flight
 
 // NW waves per workgroup share the (tap, ci-tile) pairs; 8 for the 64x64 layer so that accumulators + staging registers stay <= 128
-template <int KH, int KW, int CT, int NT, int NW>
+template <int KH, int KW, int CT, int NT, int NW, bool MASK = false>
 __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) {
   constexpr int NTHR = NW * 64, HTH = NW;
   constexpr int IR = HTH + KH - 1, IC = HTW + KW - 1;
@@ -1512,7 +1581,12 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
   // global -> registers -> LDS staging, software-pipelined: the next tile's loads are issued before this tile's MFMAs and land
   // while they run.  Loads are unconditional (clamped addresses); image borders and channel tails are masked when written.
   constexpr int NXL = (IR * IC * CT * 2 + NTHR - 1) / NTHR, NZL = (HTH * HTW * NT * 2 + NTHR - 1) / NTHR;
-  uint4 px[NXL], pz[NZL];
+  uint4 px[NXL], pz[NZL], pm[MASK ? NZL : 1];
+  auto relu_keep = [](unsigned g, unsigned m) {                  // two packed bf16: keep g where the activation m is > 0
+    const unsigned lo = ((m & 0x8000u) == 0u && (m & 0x7FFFu) != 0u) ? 0xFFFFu : 0u;
+    const unsigned hi = ((m & 0x80000000u) == 0u && (m & 0x7FFF0000u) != 0u) ? 0xFFFF0000u : 0u;
+    return g & (lo | hi);
+  };
   auto chan_mask = [](uint4 v, int nv, bool in) {               // keep the first nv (of 8) bf16 lanes
     const unsigned m0 = nv >= 2 ? ~0u : (nv == 1 ? 0xFFFFu : 0u), m1 = nv >= 4 ? ~0u : (nv == 3 ? 0xFFFFu : 0u);
     const unsigned m2 = nv >= 6 ? ~0u : (nv == 5 ? 0xFFFFu : 0u), m3 = nv >= 8 ? ~0u : (nv == 7 ? 0xFFFFu : 0u);
@@ -1543,6 +1617,10 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
       gx = gx >= a.W ? a.W - 1 : gx;
       const int c = c8 * 8 + 8 <= a.lddz ? c8 * 8 : 0;
       pz[i] = *reinterpret_cast<const uint4*>(a.dz + (unsigned)((gy * a.W + gx) * a.lddz + c));
+      if constexpr (MASK) {
+        const int cm = c8 * 8 + 8 <= a.ldmask ? c8 * 8 : 0;
+        pm[i] = *reinterpret_cast<const uint4*>(a.mask + (unsigned)((gy * a.W + gx) * a.ldmask + cm));
+      }
     }
   };
   auto write_tile = [&](int tile) {
@@ -1561,7 +1639,14 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
       const int c8 = e % (NT * 2), p = e / (NT * 2);
       const int gy = oy0 + p / HTW, gx = ox0 + p % HTW;
       const bool in = gy < a.H && gx < a.W;
-      if (e < HTH * HTW * NT * 2) *reinterpret_cast<uint4*>(zs + p * COP + c8 * 8) = chan_mask(pz[i], a.Cout - c8 * 8, in);
+      uint4 g = pz[i];
+      if constexpr (MASK) {
+        g.x = relu_keep(g.x, pm[i].x);
+        g.y = relu_keep(g.y, pm[i].y);
+        g.z = relu_keep(g.z, pm[i].z);
+        g.w = relu_keep(g.w, pm[i].w);
+      }
+      if (e < HTH * HTW * NT * 2) *reinterpret_cast<uint4*>(zs + p * COP + c8 * 8) = chan_mask(g, a.Cout - c8 * 8, in);
     }
   };
 
@@ -1642,7 +1727,14 @@ int launch_wgrad_h(const WgradArgsH& a, int CT, int NT, int nblk, hipStream_t st
   dim3 grid(nblk);
 #define ZT_WG(ct, nt, nw) hipLaunchKernelGGL((wgrad_mfma_bf16_kernel<KH, KW, ct, nt, nw>), grid, dim3(nw * 64), 0, stream, a); return 0
   if (CT == 1 && NT == 3) { ZT_WG(1, 3, 4); }
-  if (CT == 1 && NT == 4) { ZT_WG(1, 4, 4); }
+  if (CT == 1 && NT == 4) {
+    if (a.mask) {
+      hipLaunchKernelGGL((wgrad_mfma_bf16_kernel<KH, KW, 1, 4, 4, true>), grid, dim3(256), 0, stream, a);
+      return 0;
+    }
+    ZT_WG(1, 4, 4);
+  }
+  if (a.mask) return ZT_EINVAL;                                  // the folded ReLU mask exists for the thin-input 64-cout layer only
   if (CT == 3 && NT == 3) { ZT_WG(3, 3, 4); }
   if (CT == 3 && NT == 1) { ZT_WG(3, 1, 4); }
   if (CT == 4 && NT == 4) { ZT_WG(4, 4, 8); }
@@ -1769,7 +1861,8 @@ extern "C" int zt_repack_conv_weight_f32(const float* src, float* dst, int Cout,
 static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
                             const void* w, int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode,
                             int Cout, int KH, int KW, int stride, int padH, int padW, int act, float alpha,
-                            const void* aux, int ldaux, int epi, int variant, void* y2, int ldy2, int esplit, hipStream_t stream) {
+                            const void* aux, int ldaux, int epi, int variant, void* y2, int ldy2, int esplit, hipStream_t stream,
+                            float* stats = nullptr) {
   ZT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && out_mode >= 0 && out_mode <= 2);
   ZT_REQUIRE(epi >= 0 && epi <= 5 && (epi < 4 || (out_mode == 0 && variant == 2)) && (epi != 4 || (y2 && esplit > 0 && esplit < Cout)));
   ZT_REQUIRE(ldx % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
@@ -1782,7 +1875,7 @@ static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, 
   a.Wo = (W + 2 * padW - KW) / stride + 1;
   a.Cout = Cout; a.CoutP = CoutP; a.ldk = ldk; a.ldy = ldy; a.ldaux = ldaux;
   a.padH = padH; a.padW = padW; a.act = act; a.epi = epi; a.out_mode = out_mode; a.alpha = alpha;
-  a.y2 = (zt_bf16*)y2; a.ldy2 = ldy2; a.esplit = esplit;
+  a.y2 = (zt_bf16*)y2; a.ldy2 = ldy2; a.esplit = esplit; a.stats = stats;
   a.dbg = variant >= 64 ? (variant - 64) : (variant >= 32 ? (variant - 32) : (variant >= 16 ? (variant - 16) : 0));   // tuning ablations, see tools/bench_conv.py / bench_small.py
   if (variant >= 64) variant = 2;
   if (variant >= 32) variant = 3;
@@ -1830,6 +1923,7 @@ static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, 
                      ((Cout == 64 && (Cin <= 16 || Cin == 56 || Cin == 64)) || (Cout == 48 && (Cin <= 16 || Cin == 40 || Cin == 48)));
   ZT_REQUIRE(variant != 3 || rs_ok);
   static const int rs_auto = getenv("ZT_CONV_RS") ? atoi(getenv("ZT_CONV_RS")) : 1;
+  if (stats && !(rs_ok && variant == 3)) return ZT_EINVAL;      // fused statistics exist in the register-stationary kernel only
   if (rs_ok && (variant == 3 || (variant == 0 && rs_auto && (long long)zt_cdiv(a.Wo, TW) * zt_cdiv(a.Ho, 8) >= 1024))) {
     int rcp = launch_conv_rs(a, stream);
     if (rcp) return rcp;
@@ -1875,6 +1969,28 @@ extern "C" int zt_conv2d_nhwc_bf16_ex(const void* x, const void* x2, int csplit,
                           act, alpha, aux, ldaux, epi, epi >= 4 ? 2 : 0, y2, ldy2, esplit, stream);
 }
 
+extern "C" int zt_chan_stats_nhwc(const void* x, int dt, int ldx, int N, int HW, int C, int nblk, float* partial, hipStream_t stream);
+
+extern "C" int zt_conv3x3_bn_stats_bf16(const void* x, int ldx, int H, int W, int Cin, const void* w, int CoutP, int ldk, const float* bias,
+                                        void* y, int ldy, int Cout, float* stats, int stats_blocks, hipStream_t stream) {
+  ZT_REQUIRE(x && w && y && stats && stats_blocks == 512 && Cout % 8 == 0);
+  hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * (size_t)stats_blocks * 2 * Cout, stream);
+  if (e != hipSuccess) return (int)e;
+  const char* mt = getenv("ZT_STATS_FUSE_MIN_TILES");          // tests force the fused kernel onto small images
+  const long long min_tiles = mt ? atoll(mt) : 1024;
+  const bool fused = Cout == 64 && (Cin == 56 || Cin == 64) && ldx >= 8 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
+                     (long long)zt_cdiv(W, TW) * zt_cdiv(H, 8) >= min_tiles && !(getenv("ZT_CONV_RS") && atoi(getenv("ZT_CONV_RS")) == 0);
+  if (fused)
+    return conv2d_bf16_impl(x, nullptr, 0, ldx, 0, 1, H, W, Cin, w, CoutP, ldk, bias, y, ldy, 0, Cout, 3, 3, 1, 1, 1, 0, 1.f, nullptr, 0, 0, 3,
+                            nullptr, 0, 0, stream, stats);
+  int rc = conv2d_bf16_impl(x, nullptr, 0, ldx, 0, 1, H, W, Cin, w, CoutP, ldk, bias, y, ldy, 0, Cout, 3, 3, 1, 1, 1, 0, 1.f, nullptr, 0, 0, 0,
+                            nullptr, 0, 0, stream);
+  if (rc) return rc;
+  const int HW = H * W;
+  int nblk = HW / 64 < 1 ? 1 : (HW / 64 > stats_blocks ? stats_blocks : HW / 64);
+  return zt_chan_stats_nhwc(y, 1, ldy, 1, HW, Cout, nblk, stats, stream);
+}
+
 extern "C" int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
                                    const void* w, int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout,
                                    int KH, int KW, int stride, int padH, int padW, int act, float alpha, const void* aux,
@@ -1885,13 +2001,14 @@ extern "C" int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, in
 
 extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout,
                                          int KH, int KW, float* slab, size_t slab_bytes, float* grad_w, float* grad_b,
-                                         int accumulate, hipStream_t stream) {
+                                         int accumulate, const void* relu_mask, int ldmask, hipStream_t stream) {
   ZT_REQUIRE(x && dz && slab && grad_w && ldx % 8 == 0 && lddz % 8 == 0);
+  ZT_REQUIRE(!relu_mask || (ldmask % 8 == 0 && ((uintptr_t)relu_mask & 15) == 0 && KH == 3 && Cin <= 16 && Cout == 64));
   ZT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dz & 15) == 0);
   int CT = (Cin + 15) / 16, NT = (Cout + 15) / 16;
   WgradArgsH a;
   a.x = (const zt_bf16*)x; a.dz = (const zt_bf16*)dz; a.slab = slab; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.Cout = Cout;
-  a.lddz = lddz;
+  a.lddz = lddz; a.mask = (const zt_bf16*)relu_mask; a.ldmask = ldmask;
   a.tilesX = zt_cdiv(W, HTW);
   a.ntiles = a.tilesX * zt_cdiv(H, (CT == 4 && NT == 4) ? 8 : 4);      // tile rows = waves of the variant (launch_wgrad_h)
   size_t per = ((size_t)KH * KW * CT * 16 * NT * 16 + NT * 16) * sizeof(float);

@@ -47,6 +47,29 @@ __global__ void __launch_bounds__(256) pack_nhwc_kernel(T* __restrict__ dst, int
   for (; k < ld; ++k) ZtIO<T>::st(d + k, 0.f);
 }
 
+// bf16 fast path (LD = 8 or 16 channels per pixel: every thin network input): all channel planes of the pixel are loaded first
+// (coalesced, independent), packed to bf16 and written with one or two 16-byte stores (the generic kernel issues LD 2-byte
+// stores per pixel and ran at 1.8 TB/s).
+struct PackPlanes {
+  const float* ch[16];
+  int nch;
+};
+
+template <int LD>
+__global__ void __launch_bounds__(256) pack_nhwc_bf16_kernel(zt_bf16* __restrict__ dst, long long HW, PackPlanes s) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW) return;
+  float v[LD];
+#pragma unroll
+  for (int k = 0; k < LD; ++k) v[k] = k < s.nch ? s.ch[k][i] : 0.f;          // uniform predicate
+  unsigned w[LD / 2];
+#pragma unroll
+  for (int k = 0; k < LD / 2; ++k) w[k] = zt_f2bf2(v[2 * k], v[2 * k + 1]);
+  uint4* d = reinterpret_cast<uint4*>(dst + i * LD);
+#pragma unroll
+  for (int k = 0; k < LD / 8; ++k) d[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+
 // model.py:149-152 (+ loss.py:54): L2 = clamp(x - n); L_pred1/2 = L11/12 - n11/12; (den1, den2) = pd(L2)
 __global__ void __launch_bounds__(256) d1_tail_kernel(const float* __restrict__ x, const float* __restrict__ n,
                                                       const float* __restrict__ L11, const float* __restrict__ n11,
@@ -271,6 +294,18 @@ extern "C" int zt_pack_nhwc(void* dst, int dt, int ld, long long HW, const float
   PackSrc s;
   s.p[0] = s0; s.p[1] = s1; s.p[2] = s2; s.p[3] = s3;
   s.c[0] = c0; s.c[1] = c1; s.c[2] = c2; s.c[3] = c3;
+  if (dt != 0 && (ld == 8 || ld == 16) && ((uintptr_t)dst & 15) == 0) {
+    PackPlanes pl;
+    pl.nch = 0;
+    for (int j = 0; j < 4; ++j)
+      for (int c = 0; c < s.c[j]; ++c) pl.ch[pl.nch++] = s.p[j] + (size_t)c * HW;
+    for (int k = pl.nch; k < 16; ++k) pl.ch[k] = nullptr;
+    const dim3 grid((unsigned)zt_cdivl(HW, 256));
+    if (ld == 8) hipLaunchKernelGGL(pack_nhwc_bf16_kernel<8>, grid, dim3(256), 0, stream, (zt_bf16*)dst, HW, pl);
+    else hipLaunchKernelGGL(pack_nhwc_bf16_kernel<16>, grid, dim3(256), 0, stream, (zt_bf16*)dst, HW, pl);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+  }
   if (dt == 0) hipLaunchKernelGGL(pack_nhwc_kernel<float>, dim3((unsigned)zt_cdivl(HW, 256)), dim3(256), 0, stream, (float*)dst, ld, HW, s);
   else hipLaunchKernelGGL(pack_nhwc_kernel<zt_bf16>, dim3((unsigned)zt_cdivl(HW, 256)), dim3(256), 0, stream, (zt_bf16*)dst, ld, HW, s);
   ZT_LAUNCH_CHECK();

@@ -117,9 +117,12 @@ class Engine:
         f = self._conv(CV(u, 0, 9), "enhance.in_conv.0", p["enhance.in_conv.0.bias"], 64, 3, "relu")
         feats, zs, stats = [f], [], []
         for _ in range(3):
-            z = self._conv(f, "enhance.conv.0", p["enhance.conv.0.bias"], 64, 3, None)
+            if self.training and self.dt:     # bf16 mode: BatchNorm statistics come out of the convolution's store phase
+                z, part = o.conv3x3_bn_stats_bf16(f, wd["enhance.conv.0"], p["enhance.conv.0.bias"], 64)
+            else:
+                z = self._conv(f, "enhance.conv.0", p["enhance.conv.0.bias"], 64, 3, None)
+                part = o.chan_stats(z) if self.training else None
             if self.training:
-                part = o.chan_stats(z)
                 st = o.norm_finalize(part, 1, 64, H * W, 1, p["enhance.conv.1.weight"], p["enhance.conv.1.bias"],
                                      b["enhance.conv.1.running_mean"], b["enhance.conv.1.running_var"],
                                      b["enhance.conv.1.num_batches_tracked"], 0.1)
@@ -150,10 +153,14 @@ class Engine:
                                eval_mode=not self.training)
             self._wgrad(feats[i], dz, 64, 3, "enhance.conv.0")
             df = self._conv(dz, "enhance.conv.0/T", None, 64, 3, None, aux=df, epi=3)
-        # through the in_conv ReLU: mask by the saved activation (epi 2 of a 1x1 identity is overkill -> dedicated op)
-        dz0 = self._newa(1, H, W, 64)
-        self.lib.call("zt_relu_mask_nhwc", df, self.dt, 64, feats[0], 64, dz0, 64, H * W, 64, self._stream())
-        self._wgrad(CV(u, 0, 9), dz0, 64, 3, "enhance.in_conv.0")
+        # through the in_conv ReLU (its input needs no gradient, so only the weight gradient consumes the masked df)
+        if self.dt:         # bf16: the mask [feats[0] > 0] is applied while the weight-gradient kernel stages df
+            o.conv2d_wgrad_bf16(CV(u, 0, 9), df, 64, 3, 3, g["enhance.in_conv.0.weight"], accumulate=True,
+                                grad_b=g["enhance.in_conv.0.bias"], relu_mask=feats[0])
+        else:
+            dz0 = self._newa(1, H, W, 64)
+            self.lib.call("zt_relu_mask_nhwc", df, self.dt, 64, feats[0], 64, dz0, 64, H * W, 64, self._stream())
+            self._wgrad(CV(u, 0, 9), dz0, 64, 3, "enhance.in_conv.0")
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, inp, cache_fn=None, keep=True):

@@ -398,12 +398,26 @@ class Ops:
         self._ev_end(tok)
         return out
 
-    def conv2d_wgrad_bf16(self, x, dz, Cout, KH, KW, grad_w, accumulate=False, slab=None, grad_b=None):
+    def conv3x3_bn_stats_bf16(self, x, wdev, bias, Cout):
+        """y = conv3x3(x) + bias (bf16 nhwc) together with the BatchNorm statistics of y: -> (y, partial [1, 512, 2, Cout])."""
+        x = _cv(x)
+        assert x.t.dtype == torch.bfloat16 and wdev.dtype == torch.bfloat16 and x.N == 1 and wdev.shape[0] == 9
+        out = torch.empty((1, x.H, x.W, Cout), dtype=torch.bfloat16, device=x.t.device)
+        part = torch.empty((1, 512, 2, Cout), dtype=torch.float32, device=x.t.device)
+        tok = self._ev_begin(self.profile["match"].get((3, 3, 1, x.C, Cout, x.H, x.W))) if self.profile else None
+        self.lib.call("zt_conv3x3_bn_stats_bf16", x.ptr, x.ld, x.H, x.W, x.C, wdev, wdev.shape[1], wdev.shape[2], bias, out, Cout, Cout, part, 512,
+                      self._s(x.t))
+        self._ev_end(tok)
+        return out, part
+
+    def conv2d_wgrad_bf16(self, x, dz, Cout, KH, KW, grad_w, accumulate=False, slab=None, grad_b=None, relu_mask=None):
+        """relu_mask: activation tensor (nhwc bf16) of the ReLU that follows the layer; dz is used as dz * [relu_mask > 0]."""
         x, dz = _cv(x), _cv(dz)
+        mk = _cv(relu_mask) if relu_mask is not None else None
         assert x.t.dtype == torch.bfloat16 and dz.t.dtype == torch.bfloat16
         assert x.N == 1 and (x.H, x.W) == (dz.H, dz.W) and dz.C >= Cout
         assert tuple(grad_w.shape) == (Cout, x.C, KH, KW) and grad_w.is_contiguous() and grad_w.dtype == torch.float32
         slab = self.slab(x.t.device) if slab is None else slab
         self.lib.call("zt_conv2d_wgrad_nhwc_bf16", x.ptr, x.ld, dz.ptr, dz.ld, x.H, x.W, x.C, Cout, KH, KW, slab, slab.numel() * 4,
-                      grad_w, grad_b, int(accumulate), self._s(x.t))
+                      grad_w, grad_b, int(accumulate), mk.ptr if mk else None, mk.ld if mk else 0, self._s(x.t))
         return grad_w

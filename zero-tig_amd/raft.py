@@ -174,7 +174,7 @@ class RaftPlan:
         lib.call("zt_raft_flow_step", st.coords1, delta, ldd, h, w, st.F4, 4, HX.data_ptr() + st.es * 382, 384, st.FIN, st.ldfin, dt, s)
         st.CF, st.RH, st.ZR = self._new(1, h, w, 256), self._new(1, h, w, 128), self._new(1, h, w, 256)
         st.CORR = self._new(1, h, w, 328 if self.h else 324, zero=True)
-        st.delta = None
+        st.delta = self._new(1, h, w, 4, dtype=torch.float32, zero=True) if self.h else None   # flow-head output, reused every iteration
         return st
 
     def refine_step(self, st):
@@ -195,7 +195,7 @@ class RaftPlan:
             self._conv(CV(RH), g + "convq" + sfx, 128, k, pad=pad, act="tanh", x2=CV(HX, 128, 256), out=CV(HX, 0, 128),
                        aux=CV(st.ZR, 0, 128), epi=5)
         fh = self._conv(CV(HX, 0, 128), "update_block.flow_head.conv1", 256, 3, act="relu")
-        st.delta = self._conv(fh, "update_block.flow_head.conv2", 2, 3, out_f32=True)       # fp32 [..,4]
+        st.delta = self._conv(fh, "update_block.flow_head.conv2", 2, 3, out_f32=True, out=st.delta)       # fp32 [..,4]
         lib.call("zt_raft_flow_step", st.coords1, st.delta, st.delta.shape[-1], h, w, st.F4, 4, HX.data_ptr() + st.es * 382, 384,
                  st.FIN, st.ldfin, dt, s)
 
