@@ -56,6 +56,72 @@ class RLVDataLoader(_Base):
         return out
 
 
+def _list_file(root, name):
+    with open(os.path.join(root, name)) as fh:
+        lines = [l.strip() for l in fh if l.strip()]
+    assert lines, "No input data."
+    return lines
+
+
+class DidDataloader(_Base):
+    """DID layout (reference multi_read_data.py:144-199): <root>/<task>_list.txt names folders; frames are
+    input/<folder>/*.{jpg,png}, sorted by their integer file stem inside each folder."""
+
+    def name(self):
+        return "DID"
+
+    def list_files(self, root, task):
+        assert task in ("train", "test"), "Invalid phase: " + str(task)
+        out = []
+        for folder in _list_file(root, task + "_list.txt"):
+            out += _natural(glob.glob(os.path.join(root, "input", folder, "*.jpg")) + glob.glob(os.path.join(root, "input", folder, "*.png")))
+        return out
+
+
+class SDSDDataloader(_Base):
+    """SDSD layout (reference multi_read_data.py:202-318): <root>/{indoor,outdoor}/{indoor,outdoor}_png/<pair>/ with the pair
+    directories of a phase listed in <root>/sdsd_{in,out}_{train,test}.txt; ONE low-light image per pair directory (the first
+    file whose path contains neither 'gt' nor 'normal', else the first file); each subset sorted by integer file stem."""
+
+    def name(self):
+        return "SDSD"
+
+    def list_files(self, root, task):
+        assert task in ("train", "test"), "Invalid phase: " + str(task)
+        out = []
+        for subset, prefix in (("indoor", "in"), ("outdoor", "out")):
+            lst = "sdsd_%s_%s.txt" % (prefix, task)
+            png = os.path.join(root, subset, subset + "_png")
+            if not (os.path.isdir(os.path.join(root, subset)) and os.path.exists(os.path.join(root, lst)) and os.path.isdir(png)):
+                continue
+            sub = []
+            for pair in _list_file(root, lst):
+                d = os.path.join(png, pair)
+                if not os.path.isdir(d):
+                    continue
+                files = sorted(glob.glob(os.path.join(d, "*.png"))) + sorted(glob.glob(os.path.join(d, "*.jpg")))
+                low = [f for f in files if "gt" not in f.lower() and "normal" not in f.lower()]
+                if low or files:
+                    sub.append((low or files)[0])
+            out += _natural(sub)
+        return out
+
+
+class DefaultDataset(_Base):
+    """Any other dataset name (e.g. `underwater`): every file below the root, hidden files skipped, sorted by integer file stem
+    (reference multi_read_data.py:29-71 -- which is truncated upstream: no `name()` / `__len__`, so `--dataset underwater`
+    crashes there at create_data.py:16; this is the loader that code was evidently meant to be)."""
+
+    def name(self):
+        return "Default"
+
+    def list_files(self, root, task):
+        out = []
+        for r, _, names in os.walk(root):
+            out += [os.path.join(r, n) for n in names if not n.startswith(".") and n.lower().endswith((".png", ".jpg", ".jpeg", ".bmp"))]
+        return _natural(out)
+
+
 class FolderSequenceDataset(_Base):
     """Generic layout: <root>/<sequence>/*.png (every sub-folder is one sequence)."""
 

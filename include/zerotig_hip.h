@@ -192,6 +192,16 @@ int zt_clip_adam_f32(float* p, const float* g, float* m, float* v, long long n, 
 int zt_axpy_dev_f32(float* y, const float* x, const float* alpha, long long n, zt_stream_t stream);
 
 
+/* ---- output side (zt_io.hip): predict.py:57-61 save_images and evals.py:83-85 PSNR on the device -------------------------
+ * zt_quantize_u8_hwc: planar fp32 [3][H][W] in [0,1] -> interleaved uint8 [H][W][3] (what PIL / cv2 write);
+ *   mode 0 = clip(x*255, 0, 255) truncated (predict.py / train.py save_images), mode 1 = np.round(x*255) (evals.py:83-84).
+ * zt_sqdiff_u8_f32: out[0] = sum_i (round(a_i*255) - round(b_i*255))^2, exact 64-bit integer; PSNR = 10 log10(255^2 n / out).
+ *   partial: nblk x 8 bytes of workspace. */
+int zt_quantize_u8_hwc(const float* src, unsigned char* dst, int H, int W, int mode, zt_stream_t stream);
+int zt_sqdiff_u8_f32(const float* a, const float* b, long long n, unsigned long long* partial, int nblk, unsigned long long* out,
+                     zt_stream_t stream);
+
+
 /* ---- hardware self-test probes (zt_probe.hip): pin the test emulator's model of gfx950 instructions to the chip ----- */
 /* ds_read_b64_tr_b16 on a [16][64] image of 16-bit codes: out[lane*4+q]; bf16 MFMA 16x16x32: D[16][16] = A[16][32] B[32][16] */
 int zt_probe_tr16(const unsigned short* img, unsigned short* out, int col0, zt_stream_t stream);

@@ -156,3 +156,89 @@ def test_bench_gpus_flag_launches_one_rank_per_gpu():
     env.update(RANK="1", LOCAL_RANK="1", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and json.loads(r.stdout.strip())["RANK"] == "1"
+
+
+def test_dataloader_did_sdsd_default_layouts(tmp_path):
+    """Reference multi_read_data.py:144-318 layouts: DID list file + input/<folder>/*.{jpg,png}; SDSD pair directories listed per
+    subset, one low-light frame per pair; any other dataset name walks the tree (the upstream DefaultDataset is truncated)."""
+    from PIL import Image
+    cd = importlib.import_module("dataloader.create_data")
+
+    def img(path, v):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        Image.fromarray(np.full((6, 8, 3), v, np.uint8)).save(path)
+    did = str(tmp_path / "did")
+    for i in (3, 1, 2):
+        img(os.path.join(did, "input", "V1", "%d.jpg" % i), i)
+    img(os.path.join(did, "input", "V2", "7.png"), 7)
+    open(os.path.join(did, "train_list.txt"), "w").write("V1\nV2\n")
+    ds = cd.CreateDataset(argparse.Namespace(dataset="DID", lowlight_images_path=did), "train")
+    assert ds.name() == "DID" and [ds[i][1] for i in range(len(ds))] == ["1", "2", "3", "7"]
+    assert tuple(ds[0][0].shape) == (3, 1080, 1920)
+    sd = str(tmp_path / "sdsd")
+    for pair, stem in (("pair5", 5), ("pair2", 2)):
+        img(os.path.join(sd, "indoor", "indoor_png", pair, "%d.png" % stem), stem)
+        img(os.path.join(sd, "indoor", "indoor_png", pair, "%d_gt.png" % stem), 200)
+    img(os.path.join(sd, "outdoor", "outdoor_png", "o1", "9.png"), 9)
+    open(os.path.join(sd, "sdsd_in_test.txt"), "w").write("pair5\npair2\nmissing\n")
+    open(os.path.join(sd, "sdsd_out_test.txt"), "w").write("o1\n")
+    ds = cd.CreateDataset(argparse.Namespace(dataset="SDSD", lowlight_images_path=sd), "test")
+    assert ds.name() == "SDSD" and [ds[i][1] for i in range(len(ds))] == ["2", "5", "9"]
+    uw = str(tmp_path / "uw")
+    for i in (12, 11):
+        img(os.path.join(uw, "clipA", "%d.png" % i), i)
+    open(os.path.join(uw, ".hidden.png"), "w").write("x")
+    ds = cd.CreateDataset(argparse.Namespace(dataset="underwater", lowlight_images_path=uw), "train")
+    x, name, path, last = ds[1]
+    assert len(ds) == 2 and name == "12" and last.endswith("11.png") and abs(float(x.max()) - 12 / 255) < 1e-6
+
+
+def test_output_side_quantise_and_psnr(backend, oracle):
+    """predict.py:57-61 save_images and evals.py:83-85 PSNR on the device vs their numpy definitions (bit / integer exact)."""
+    ops, dev, _ = backend
+    g = torch.Generator().manual_seed(5)
+    H, W = 37, 53                                   # HW not a multiple of 4: ragged tail
+    a = torch.rand(1, 3, H, W, generator=g)
+    a[0, 0, 0, :6] = torch.tensor([0.0, 1.0, 0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255])      # ties -> half-to-even
+    b = torch.clamp(a + 0.02 * torch.randn(1, 3, H, W, generator=g), 0, 1)
+    ref0 = np.clip(np.transpose(a[0].numpy(), (1, 2, 0)) * 255.0, 0, 255.0).astype("uint8")
+    ref1 = np.round(np.transpose(a[0].numpy(), (1, 2, 0)) * 255).astype(np.uint8)
+    assert np.array_equal(ops.quantize_u8(a.to(dev), 0).cpu().numpy(), ref0)
+    assert np.array_equal(ops.quantize_u8(a.to(dev), 1).cpu().numpy(), ref1)
+    q = lambda t: np.round(t.numpy().astype(np.float32) * np.float32(255)).astype(np.int64)
+    sq = int(((q(a) - q(b)) ** 2).sum())                                       # cv2.PSNR's sum, in exact integers
+    assert ops.psnr_u8(a.to(dev), b.to(dev)) == 10.0 * np.log10(255.0 ** 2 * a.numel() / sq)
+    assert abs(ops.psnr_u8(a.to(dev), b.to(dev)) - oracle.psnr_u8(a, b)) < 1e-6   # the oracle averages in fp32
+    assert ops.psnr_u8(a.to(dev), a.to(dev)) == float("inf")
+
+
+def test_resume_checkpoint_roundtrip(backend, synth, tmp_path):
+    """model (223 reference keys) + Adam moments + step survive a save / load; training continues bit-identically."""
+    ops, dev, _ = backend
+    optim = importlib.import_module("zero-tig_amd.optim")
+    net_mod = importlib.import_module("zero-tig_amd.network")
+    sys.path.insert(0, ROOT)
+    utils = importlib.import_module("utils.utils")
+    xs = [f.to(dev) for f in frames(synth, 3, 48, 64)]
+
+    def make():
+        net = net_mod.Network(argparse.Namespace(dataset="RLV", of_scale=3), ops=ops)
+        st = synth.make_state(1)
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()})
+        net = net.to(dev).train()
+        return net, optim.ClipAdam(net)
+    net, opt = make()
+    ts = optim.TrainStep(net, opt, use_graph=False)
+    ts(xs[0], True)
+    ts(xs[1], True)
+    ck = str(tmp_path / "resume.pt")
+    utils.save_checkpoint(net, opt, ck, epoch=1, step=2)
+    assert set(torch.load(ck)["model"].keys()) == set(net.state_dict().keys()) and len(net.state_dict()) == 223
+    l_ref = float(ts(xs[2], True))
+    net2, opt2 = make()
+    assert utils.load_checkpoint(net2, opt2, ck) == (1, 2) and opt2.t == 2
+    l_res = float(optim.TrainStep(net2, opt2, use_graph=False)(xs[2], True))
+    assert l_res == l_ref and torch.equal(opt.fp.flat, opt2.fp.flat) and torch.equal(opt.m, opt2.m)
+    plain = str(tmp_path / "plain.pt")
+    utils.save(net, plain)
+    assert utils.load_checkpoint(net2, None, plain) == (0, 0)

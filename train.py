@@ -36,12 +36,14 @@ parser.add_argument("--of_scale", type=int, default=3, help="downscale factor fo
 parser.add_argument("--dataset", type=str, default="RLV", help="dataset name")
 parser.add_argument("--num_workers", type=int, default=0, help="dataloader workers")
 parser.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"], help="bf16 throughput mode / fp32 parity mode")
+parser.add_argument("--resume", type=str, default=None, help="resume file written every epoch (model + Adam moments + step + loop position)")
 parser.add_argument("--reference_eval_quirk", action="store_true", help="stay in eval() after the first epoch like the reference (train.py:138)")
 
 
 def save_images(tensor):
-    im = np.transpose(tensor[0].cpu().float().numpy(), (1, 2, 0))
-    return np.clip(im * 255.0, 0, 255.0).astype("uint8")
+    """predict.py:57-61: clip(x * 255, 0, 255).astype(uint8), HWC -- quantised and interleaved on the device (6 MB instead of
+    25 MB per 1080p frame over PCIe)."""
+    return utils.quantize_u8(tensor).cpu().numpy()
 
 
 def main():
@@ -103,9 +105,12 @@ def main():
                                               num_workers=args.num_workers, shuffle=False)
     test_queue = torch.utils.data.DataLoader(test_set, batch_size=1, pin_memory=True, num_workers=args.num_workers, shuffle=False)
 
-    total_step = 0
+    total_step, first_epoch = 0, 0
+    if args.resume:
+        first_epoch, total_step = utils.load_checkpoint(model, optimizer, args.resume)
+        logging.info("resumed from %s: epoch %d, step %d", args.resume, first_epoch, total_step)
     model.train()
-    for epoch in range(args.epochs):
+    for epoch in range(first_epoch, args.epochs):
         losses = []
         for it, (inp, img_name, img_path, last_img_path) in enumerate(train_queue):
             if it >= steps_per_epoch:
@@ -121,7 +126,8 @@ def main():
             logging.info("train-epoch %03d %03d %f", epoch, it, losses[-1])
         logging.info("train-epoch %03d %f", epoch, np.average(losses))
         if rank == 0:
-            utils.save(model, os.path.join(model_path, "weights_%d.pt" % epoch))
+            utils.save(model, os.path.join(model_path, "weights_%d.pt" % epoch))        # the reference's plain state_dict (train.py:135)
+        utils.save_checkpoint(model, optimizer, os.path.join(model_path, "resume.pt"), epoch=epoch + 1, step=total_step)
         # every rank switches mode together: under DP the gradients that get all-reduced must come from the same BN mode
         model.eval()
         if rank == 0:

@@ -77,6 +77,17 @@ class InputPadder:                                           # utils.py:233-251 
         return x[..., c[0]:c[1], c[2]:c[3]]
 
 
+def quantize_u8(tensor, round_half_even=False):
+    """[1,3,H,W] in [0,1] on the device -> uint8 [H,W,3] on the device: predict.py:57-61 `save_images` (truncation) or, with
+    round_half_even, evals.py:83-84 `np.round(x * 255).astype(np.uint8)`."""
+    return _ops().quantize_u8(_prep(tensor), 1 if round_half_even else 0)
+
+
+def psnr(img, gt):
+    """evals.py:83-85: cv2.PSNR(np.round(img * 255), np.round(gt * 255)) computed on the device (exact integer reduction)."""
+    return _ops().psnr_u8(_prep(img), _prep(gt))
+
+
 def count_parameters_in_MB(model):                           # utils.py:81-82
     return sum(int(np.prod(v.size())) for name, v in model.named_parameters() if "auxiliary" not in name) / 1e6
 
@@ -87,6 +98,36 @@ def save(model, model_path):                                 # utils.py:94-95
 
 def load(model, model_path):                                 # utils.py:98-99
     model.load_state_dict(torch.load(model_path))
+
+
+def save_checkpoint(model, optimizer, path, epoch=0, step=0):
+    """Resume state next to the reference's plain `state_dict` file (utils.py:94-99 has no optimizer / step state): the same 223
+    keys under "model" (so `load` / the key-filtered merges of train.py:86-92 and model.py:271-277 still apply to it) plus Adam's
+    moments and step count over the flat bucket and the loop position.  Under data parallelism the BatchNorm running statistics
+    (per rank: the reference has no SyncBN) are averaged over the ranks first, so every rank resumes from the same file."""
+    import torch.distributed as dist
+    bn = model.enhance.conv[1]
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for t in (bn.running_mean, bn.running_var):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t.div_(dist.get_world_size())
+        if dist.get_rank() != 0:
+            return
+    torch.save({"model": model.state_dict(), "optimizer": optimizer.state_dict(), "epoch": int(epoch), "step": int(step)}, path)
+
+
+def load_checkpoint(model, optimizer, path):
+    """-> (epoch, step).  Accepts a resume file of `save_checkpoint` or a plain reference-style `state_dict` (then (0, 0))."""
+    ck = torch.load(path, map_location="cpu")
+    sd = ck["model"] if isinstance(ck, dict) and "model" in ck and "optimizer" in ck else ck
+    md = model.state_dict()
+    md.update({k: v for k, v in sd.items() if k in md})
+    model.load_state_dict(md)
+    if sd is ck:
+        return 0, 0
+    if optimizer is not None:
+        optimizer.load_state_dict(ck["optimizer"])
+    return int(ck.get("epoch", 0)), int(ck.get("step", 0))
 
 
 def create_exp_dir(path, scripts_to_save=None):              # utils.py:109-118

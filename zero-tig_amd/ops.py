@@ -163,6 +163,29 @@ class Ops:
         self.lib.call("zt_ycc_flat_f32", x, out, x.numel(), self._s(x))
         return out
 
+    # ---- output side (zt_io.hip) ------------------------------------------------------------------------------
+    def quantize_u8(self, x, mode=0):
+        """[1,3,H,W] fp32 in [0,1] -> uint8 [H,W,3] on the device (mode 0: predict.py save_images truncation; 1: evals.py round)."""
+        _f32c(x)
+        _, C, H, W = x.shape
+        assert C == 3
+        out = torch.empty((H, W, 3), dtype=torch.uint8, device=x.device)
+        self.lib.call("zt_quantize_u8_hwc", x, out, H, W, int(mode), self._s(x))
+        return out
+
+    def psnr_u8(self, a, b):
+        """evals.py:83-85: cv2.PSNR of round(a*255), round(b*255) -> python float (inf when identical); one 8-byte read-back."""
+        _f32c(a), _f32c(b)
+        n = a.numel()
+        assert b.numel() == n
+        nblk = max(1, min(1024, n // 4096))
+        part = torch.empty(nblk, dtype=torch.int64, device=a.device)
+        out = torch.empty(1, dtype=torch.int64, device=a.device)
+        self.lib.call("zt_sqdiff_u8_f32", a, b, n, part, nblk, out, self._s(a))
+        import math
+        sq = int(out.item())
+        return float("inf") if sq == 0 else 10.0 * math.log10(255.0 ** 2 * n / sq)
+
     # ---- convolution family (zt_conv.hip) ---------------------------------------------------------------------
     def repack_weight(self, w, ldw=None, co_off=0, transpose_flip=False, out=None):
         """torch [Cout,Cin,KH,KW] -> device layout [KH*KW, Cin', ldw]."""

@@ -54,6 +54,19 @@ class ClipAdam:
         self.partial = torch.empty(256, dtype=torch.float32, device=dev)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
 
+    def state_dict(self):
+        """Adam moments and step count over the flat bucket, keyed by parameter name (resume state; the reference saves none)."""
+        fp = self.fp
+        sl = lambda buf: {n: buf[o:o + s].view(p.shape).detach().cpu().clone() for n, p, o, s in zip(fp.names, fp.params, fp.offsets, fp.sizes)}
+        return {"t": self.t, "exp_avg": sl(self.m), "exp_avg_sq": sl(self.v), "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        fp = self.fp
+        for n, p, o, s in zip(fp.names, fp.params, fp.offsets, fp.sizes):
+            self.m[o:o + s].copy_(sd["exp_avg"][n].reshape(-1))
+            self.v[o:o + s].copy_(sd["exp_avg_sq"][n].reshape(-1))
+        self.t = int(sd["t"])
+
     def zero_grad(self, set_to_none=False):
         self.fp.grad.zero_()
         for p, o, s in zip(self.fp.params, self.fp.offsets, self.fp.sizes):
