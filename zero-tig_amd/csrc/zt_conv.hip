@@ -481,6 +481,11 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
     w_ok[i] = co0 + co < a.CoutP ? ~0u : 0u;
   }
   const int w_grp_stride = TG * a.CoutP * a.ldk;
+  // uniform fast-path flags: a tile whose halo lies inside the image needs no zero fill, a workgroup whose couts all exist no
+  // weight mask; full channel chunks need no tail masks.  Slots below the last one are in range for every thread (compile time).
+  const bool x_interior = gy0 >= 0 && gy0 + IR <= a.H && gx0 >= 0 && gx0 + IC <= a.W;
+  const bool w_all = co0 + NT * 16 <= a.CoutP;
+  constexpr bool X_LAST_PARTIAL = (IR * IC * CPP) % 256 != 0, W_LAST_PARTIAL = (TG * NT * 16 * CPP) % 256 != 0;
   auto load_w = [&](auto sl, int c0, int grp) {
     constexpr int d = decltype(sl)::value;
     const int add = c0 + grp * w_grp_stride;
@@ -489,18 +494,21 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
     for (int i = 0; i < NWS; ++i) {
       int off = w_src[i] + add;
       if (ragged) off = c0 + q8 < a.ldk ? off : off - (c0 + q8);
-      wv[d][i] = *reinterpret_cast<const uint4*>(a.w + (unsigned)off);
+      wv[d][i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + 2u * (unsigned)off);
     }
   };
   auto write_w = [&](auto sl, int c0) {
     constexpr int d = decltype(sl)::value;
+    const bool plain = w_all && c0 + KCH <= a.ldk && c0 < a.Cin;         // uniform
     const unsigned cok = (c0 + q8 < a.ldk && c0 < a.Cin) ? ~0u : 0u;   // beyond the weight row / a padding chunk: zeros
 #pragma unroll
     for (int i = 0; i < NWS; ++i) {
-      const unsigned m = w_ok[i] & cok;
       uint4 v = wv[d][i];
-      v.x &= m; v.y &= m; v.z &= m; v.w &= m;
-      if (w_lds[i] >= 0) *reinterpret_cast<uint4*>(ws + w_lds[i]) = v;
+      if (!plain) {
+        const unsigned m = w_ok[i] & cok;
+        v.x &= m; v.y &= m; v.z &= m; v.w &= m;
+      }
+      if (!(W_LAST_PARTIAL && i == NWS - 1) || w_lds[i] >= 0) *reinterpret_cast<uint4*>(ws + w_lds[i]) = v;
     }
   };
   auto load_x = [&](auto sl, int c0) {
@@ -514,7 +522,7 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
     for (int i = 0; i < NXS; ++i) {
       int off = (second ? x_src2[i] : x_src1[i]) + cbase;
       if (ragged) off = cbase + q8 < ld ? off : off - (cbase + q8);
-      xv[d][i] = *reinterpret_cast<const uint4*>(src + (unsigned)off);
+      xv[d][i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src) + 2u * (unsigned)off);
     }
   };
   auto write_x = [&](auto sl, int c0) {
@@ -522,17 +530,24 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
     const bool second = a.x2 != nullptr && c0 >= a.csplit;
     const int cbase = second ? c0 - a.csplit : c0;
     const int climit = second ? a.Cin - a.csplit : (a.x2 ? a.csplit : a.Cin);
+    const bool full = cbase + KCH <= climit;                      // uniform: no channel tail in this chunk
     const int nv = climit - (cbase + q8);                         // valid channels of this thread's octet (ragged tail / beyond the input)
     const unsigned m0 = nv >= 2 ? ~0u : (nv == 1 ? 0xFFFFu : 0u), m1 = nv >= 4 ? ~0u : (nv == 3 ? 0xFFFFu : 0u);
     const unsigned m2 = nv >= 6 ? ~0u : (nv == 5 ? 0xFFFFu : 0u), m3 = nv >= 8 ? ~0u : (nv == 7 ? 0xFFFFu : 0u);
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
       uint4 v = xv[d][i];
-      v.x &= x_in[i] & m0;
-      v.y &= x_in[i] & m1;
-      v.z &= x_in[i] & m2;
-      v.w &= x_in[i] & m3;
-      if (x_lds[i] >= 0) *reinterpret_cast<uint4*>(xs + x_lds[i]) = v;
+      if (!(full && x_interior)) {
+        if (full) {
+          v.x &= x_in[i]; v.y &= x_in[i]; v.z &= x_in[i]; v.w &= x_in[i];
+        } else {
+          v.x &= x_in[i] & m0;
+          v.y &= x_in[i] & m1;
+          v.z &= x_in[i] & m2;
+          v.w &= x_in[i] & m3;
+        }
+      }
+      if (!(X_LAST_PARTIAL && i == NXS - 1) || x_lds[i] >= 0) *reinterpret_cast<uint4*>(xs + x_lds[i]) = v;
     }
   };
 
@@ -540,6 +555,12 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
   // multiple of PD chunks whose padding chunks are staged as zeros): with `if (more)` around the prefetch the compiler lost
   // count of the outstanding loads and put s_waitcnt vmcnt(0) in front of every LDS write, i.e. one full memory latency per
   // chunk however deep the prefetch (1.6-2.6 us per chunk on the 45 x 80 maps; measured with tools/bench_small.py).
+  float bias_q[NT];                                             // requested now: the K loop hides the latency the epilogue used to expose
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    const int co = co0 + q * 16 + l15;
+    bias_q[q] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+  }
   const int nch = (a.dbg & 4) ? 0 : (a.Cin + KCH - 1) / KCH;     // dbg 4: prologue + epilogue only
   const int last_c0 = (nch - 1) * KCH;
   if (nch > 0) {
@@ -619,7 +640,7 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
   for (int q = 0; q < NT; ++q) {
     const int co = co0 + q * 16 + l15;
     if (co >= a.Cout) continue;
-    const float b = a.bias ? a.bias[co] : 0.f;
+    const float b = bias_q[q];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -1555,7 +1576,7 @@ constexpr int HTW = 32;                 // tile = HTH rows x 32 pixels; HTH = 2 
 
 // NW waves per workgroup share the (tap, ci-tile) pairs; 8 for the 64x64 layer so that accumulators + staging registers stay <= 128
 template <int KH, int KW, int CT, int NT, int NW, bool MASK = false>
-__global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) {
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && CT == 4 && NT == 4) ? 2 : 1) wgrad_mfma_bf16_kernel(WgradArgsH a) {
   constexpr int NTHR = NW * 64, HTH = NW;
   constexpr int IR = HTH + KH - 1, IC = HTW + KW - 1;
   constexpr int CIP = CT * 16 + 8, COP = NT * 16 + 8;
@@ -1669,30 +1690,50 @@ __global__ void __launch_bounds__(NW * 64) wgrad_mfma_bf16_kernel(WgradArgsH a) 
       const int ky = tap / KW, kx = tap - ky * KW;
       aoff[pi] = (ky * IC + kx + g8 + trq) * CIP + cit * 16 + trp;
     }
-#pragma unroll 1
-    for (int r = 0; r < HTH; ++r) {
-      zt_s16x8 bv[NT];
+    // Rows in blocks of four, fully unrolled inside a block: one flat software pipeline over the 4 * PPW (row, pair) steps.  The
+    // A fragments (transposed x reads) run LA = 3 steps ahead of the MFMAs that consume them and the B fragments (dz) of a row
+    // are requested one row earlier, across the row and block boundaries (indices clamped at the tile's end): with one step of
+    // look-ahead inside a row and the B reads at the head of every row the 128+ clocks of LDS latency were exposed five-plus
+    // times per row.
+    constexpr int RB = 4, NS = RB * PPW, AD = 4, LA = 3;
+    static_assert(HTH % RB == 0 && NS % AD == 0, "block geometry");
+    zt_s16x4 alo[AD], ahi[AD];
+    zt_s16x8 bv[2][NT];
+    auto load_a = [&](auto bc, int row, auto pc) {
+      constexpr int bi = decltype(bc)::value, pi = decltype(pc)::value;
+      const zt_bf16* xr = xs + (row < HTH ? row : HTH - 1) * IC * CIP;
+      alo[bi] = zt_lds_read_tr16(xr + aoff[pi]);
+      ahi[bi] = zt_lds_read_tr16(xr + aoff[pi] + 4 * CIP);
+    };
+    auto load_b = [&](auto bc, int row) {
+      constexpr int bi = decltype(bc)::value;
+      const int rr = row < HTH ? row : HTH - 1;
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
-        zt_s16x4 lo = zt_lds_read_tr16(zs + (r * HTW + g8 + trq) * COP + q * 16 + trp);
-        zt_s16x4 hi = zt_lds_read_tr16(zs + (r * HTW + g8 + 4 + trq) * COP + q * 16 + trp);
-        bv[q] = (zt_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        zt_s16x4 lo = zt_lds_read_tr16(zs + (rr * HTW + g8 + trq) * COP + q * 16 + trp);
+        zt_s16x4 hi = zt_lds_read_tr16(zs + (rr * HTW + g8 + 4 + trq) * COP + q * 16 + trp);
+        bv[bi][q] = (zt_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
-      const zt_bf16* xr = xs + r * IC * CIP;
-      zt_s16x4 alo[2], ahi[2];
-      alo[0] = zt_lds_read_tr16(xr + aoff[0]);
-      ahi[0] = zt_lds_read_tr16(xr + aoff[0] + 4 * CIP);
-      zt_static_for<0, PPW>([&](auto pi_c) {
-        constexpr int pi = decltype(pi_c)::value;
-        constexpr int cur = pi & 1;
-        if constexpr (pi + 1 < PPW) {
-          alo[cur ^ 1] = zt_lds_read_tr16(xr + aoff[pi + 1]);
-          ahi[cur ^ 1] = zt_lds_read_tr16(xr + aoff[pi + 1] + 4 * CIP);
+    };
+    load_b(ZtIdx<0>{}, 0);
+    zt_static_for<0, LA>([&](auto sc) {
+      constexpr int st = decltype(sc)::value;
+      load_a(ZtIdx<st % AD>{}, st / PPW, ZtIdx<st % PPW>{});
+    });
+#pragma unroll 1
+    for (int r0 = 0; r0 < HTH; r0 += RB) {
+      zt_static_for<0, NS>([&](auto sc) {
+        constexpr int st = decltype(sc)::value;
+        constexpr int rl = st / PPW, pi = st % PPW, cur = st % AD;
+        if constexpr (pi == 0) load_b(ZtIdx<(rl + 1) & 1>{}, r0 + rl + 1);          // next row's dz fragments (RB is even)
+        {
+          constexpr int nx = st + LA;                                                 // may run into the next block: row r0 + RB + ..
+          load_a(ZtIdx<nx % AD>{}, r0 + nx / PPW, ZtIdx<nx % PPW>{});
         }
         __builtin_amdgcn_sched_barrier(0);
         zt_s16x8 av = (zt_s16x8){alo[cur][0], alo[cur][1], alo[cur][2], alo[cur][3], ahi[cur][0], ahi[cur][1], ahi[cur][2], ahi[cur][3]};
 #pragma unroll
-        for (int q = 0; q < NT; ++q) acc[pi][q] = zt_mfma_bf16(av, bv[q], acc[pi][q]);
+        for (int q = 0; q < NT; ++q) acc[pi][q] = zt_mfma_bf16(av, bv[rl & 1][q], acc[pi][q]);
         __builtin_amdgcn_sched_barrier(0);
       });
     }
@@ -1737,7 +1778,11 @@ int launch_wgrad_h(const WgradArgsH& a, int CT, int NT, int nblk, hipStream_t st
   if (a.mask) return ZT_EINVAL;                                  // the folded ReLU mask exists for the thin-input 64-cout layer only
   if (CT == 3 && NT == 3) { ZT_WG(3, 3, 4); }
   if (CT == 3 && NT == 1) { ZT_WG(3, 1, 4); }
-  if (CT == 4 && NT == 4) { ZT_WG(4, 4, 8); }
+  if (CT == 4 && NT == 4) {
+    static const int nw4 = getenv("ZT_WGRAD_NW4") ? atoi(getenv("ZT_WGRAD_NW4")) : 0;      // tuning hook: 4-wave / 4-row form
+    if (nw4) { ZT_WG(4, 4, 4); }
+    ZT_WG(4, 4, 8);
+  }
   if (CT == 4 && NT == 1) { ZT_WG(4, 1, 4); }
 #undef ZT_WG
   return ZT_EINVAL;
@@ -2010,7 +2055,8 @@ extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
   a.x = (const zt_bf16*)x; a.dz = (const zt_bf16*)dz; a.slab = slab; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.Cout = Cout;
   a.lddz = lddz; a.mask = (const zt_bf16*)relu_mask; a.ldmask = ldmask;
   a.tilesX = zt_cdiv(W, HTW);
-  a.ntiles = a.tilesX * zt_cdiv(H, (CT == 4 && NT == 4) ? 8 : 4);      // tile rows = waves of the variant (launch_wgrad_h)
+  const bool nw8 = CT == 4 && NT == 4 && !(getenv("ZT_WGRAD_NW4") && atoi(getenv("ZT_WGRAD_NW4")));
+  a.ntiles = a.tilesX * zt_cdiv(H, nw8 ? 8 : 4);      // tile rows = waves of the variant (launch_wgrad_h)
   size_t per = ((size_t)KH * KW * CT * 16 * NT * 16 + NT * 16) * sizeof(float);
   int want = 512;
   if (const char* e = getenv("ZT_WGRAD_BLOCKS")) want = atoi(e) > 0 ? atoi(e) : want;      // tuning hook
