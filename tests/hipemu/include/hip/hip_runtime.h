@@ -169,6 +169,7 @@ static inline float __fsub_rn(float a, float b) { volatile float r = a - b; retu
 static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
 #define __expf(x) expf(x)
 static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 
 // ---- MFMA (gfx950 lane maps) -------------------------------------------------------------------------------
 typedef float zt_emu_f32x4 __attribute__((ext_vector_type(4)));

@@ -186,6 +186,19 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(ConvArgs a) {
   }
 }
 
+// bf16 throughput mode: the activation result is rounded to bf16 (3 significant digits) right away, so the hardware
+// exp / rcp (1 ulp-ish) replace the ~25-instruction libm expansions -- per element of the issue-bound small-map epilogues
+__device__ __forceinline__ float apply_act_fast(float v, int act) {
+  switch (act) {
+    case 1: return fmaxf(v, 0.f);
+    case 2: return v > 0.f ? v : 0.2f * v;
+    case 3: return __builtin_amdgcn_rcpf(1.f + __expf(-v));
+    case 4: return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v) + 1.f);
+    case 5: return fminf(fmaxf(__builtin_amdgcn_rcpf(1.f + __expf(-v)), 0.0001f), 1.f);
+    default: return v;
+  }
+}
+
 template <int KH, int KW, int S>
 int launch_conv(const ConvArgs& a, int NT, dim3 grid_base, hipStream_t stream) {
   dim3 block(256);
@@ -428,11 +441,13 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
   __shared__ __attribute__((aligned(16))) zt_bf16 ws[TG * NT * 16 * KCHP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int t = blockIdx.x;
-  const int tx = t % a.tilesX;
-  t /= a.tilesX;
-  const int ty = t % a.tilesY;
-  const int n = t / a.tilesY;
+  // grid = (tile columns, cout groups, tile rows x images): no integer divisions in the (issue-bound) prologue
+  const int tx = blockIdx.x;
+  int ty = blockIdx.z, n = 0;
+  if (a.N > 1) {
+    n = ty / a.tilesY;
+    ty -= n * a.tilesY;
+  }
   const int co0 = blockIdx.y * (NT * 16);
   const int oy0 = ty * TH, ox0 = tx * TWm;
   const int gy0 = oy0 * S - a.padH, gx0 = ox0 * S - a.padW;
@@ -647,7 +662,7 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
       for (int j = 0; j < 4; ++j) {
         const int ox = ox0 + m * 16 + l4 * 4 + j;
         if (ox >= a.Wo) continue;
-        float v = apply_act(a.alpha * (acc[m][q][j] + b), a.act);
+        float v = apply_act_fast(a.alpha * (acc[m][q][j] + b), a.act);
         const size_t pix = (size_t)(n * a.Ho + oy) * a.Wo + ox;
         if (a.epi >= 4) {       // SepConvGRU fusions (update.py:42-58), bf16 nhwc only
           zt_bf16* yb = (zt_bf16*)a.y;
@@ -678,12 +693,14 @@ template <int KH, int KW, int S, int MT>
 int launch_conv_h(const ConvArgsH& a, int NT, unsigned gx, hipStream_t stream) {
   dim3 block(256);
   int c16 = (a.Cout + 15) / 16;
-  dim3 grid(gx, (c16 + NT - 1) / NT);
+  (void)gx;
+  if ((long long)a.tilesY * a.N > 65535) return ZT_EINVAL;
+  dim3 grid(a.tilesX, (c16 + NT - 1) / NT, a.tilesY * a.N);
   constexpr int IRc = (TH - 1) * S + KH, ICc = (16 * MT - 1) * S + KW;
   // 64-channel chunks where every chunk is full: Cin (and the split point of a two-part input) multiples of 64
   const bool wide = a.Cin % 64 == 0 && (!a.x2 || a.csplit % 64 == 0);
   // latency-bound launches (about two workgroups per CU or fewer, several channel chunks): two chunks of loads in flight
-  const bool deep = MT == 1 && (long long)grid.x * grid.y <= 1024 && a.Cin > 64;
+  const bool deep = MT == 1 && (long long)grid.x * grid.y * grid.z <= 1024 && a.Cin > 64;
 #define ZT_CH(nt)                                                                                             \
   {                                                                                                           \
     constexpr bool all1 = (KH * KW * nt * 16 + IRc * ICc) * 48 * 2 <= 72 * 1024;                              \
