@@ -259,7 +259,9 @@ class Ops:
 
     # ---- normalisation (zt_norm.hip) --------------------------------------------------------------------------
     def _nblk(self, HW):
-        return max(1, min(1024, HW // 64))
+        # one partial row per workgroup; 256 = one workgroup per CU.  More rows only lengthen the finalize kernel's serial sum
+        # (10 us with 900 rows on the 180 x 320 RAFT maps, 4 us with 256) without making the statistics pass any faster.
+        return max(1, min(256 if HW < (1 << 20) else 1024, HW // 64))
 
     def chan_stats(self, x, nblk=None):
         """-> partial [N, nblk, 2, C] (sum, sum of squares) for a CV/tensor NHWC."""
