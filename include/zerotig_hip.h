@@ -236,6 +236,17 @@ int zt_conv3x3_bn_stats_bf16(const void* x, int ldx, int H, int W, int Cin, cons
 int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout, int KH, int KW,
                               float* slab, size_t slab_bytes, float* grad_w, float* grad_b, int accumulate, const void* relu_mask,
                               int ldmask, zt_stream_t stream);
+/* Deferred, batched form of the weight gradient for a whole backward pass (bf16 mode): every call of a layer APPENDS its
+ * per-workgroup slabs (KH*KW*Cin16*Cout16 + Cout16 floats each, Cin16 / Cout16 = channel counts rounded up to 16) to that layer's slab region and reports how many it wrote
+ * (*nslab_out, host int); zt_wgrad_reduce_multi_f32 then reduces up to 16 layers in ONE launch: layer i sums nslab[i] slabs at
+ * slab[i] into grad_w[i] ([Cout][Cin][K][K]) and grad_b[i] (may be NULL), (+)= when accumulate.  All array arguments are host arrays. */
+int zt_conv2d_wgrad_partial_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout, int KH, int KW,
+                                 float* slab, size_t slab_bytes, const void* relu_mask, int ldmask, int* nslab_out, zt_stream_t stream);
+int zt_wgrad_reduce_multi_f32(int nseg, const void* const* slab, const int* nslab, const int* Cin, const int* Cout, const int* K,
+                              void* const* grad_w, void* const* grad_b, int accumulate, zt_stream_t stream);
+/* all weight repacks of a step in one launch (up to 24 entries; host arrays; square kernels K x K; same layouts as the single form) */
+int zt_repack_conv_weights_bf16_multi(int n, const void* const* src, void* const* dst, const int* Cout, const int* Cin, const int* K,
+                                      const int* CoutP, const int* ldk, const int* transpose_flip, zt_stream_t stream);
 int zt_repack_conv_weight_bf16(const float* src, void* dst, int Cout, int Cin, int KH, int KW, int CoutP, int ldk, int co_off,
                                int transpose_flip, zt_stream_t stream);
 

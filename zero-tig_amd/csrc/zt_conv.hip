@@ -380,6 +380,77 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// One launch for ALL layers of a backward pass: segment s = blockIdx.y sums the slabs that every weight-gradient call of one layer
+// appended to that layer's slab region (the three Denoise invocations, the three shared Enhancer blocks) and writes the layer's
+// grad_w / grad_b.  Same per-element arithmetic as wgrad_reduce_kernel (fixed order: bit-reproducible); replaces 23 launches of
+// ~9 us each per training step.
+constexpr int ZT_MAXSEG = 16;
+struct ReduceTable {
+  const float* slab[ZT_MAXSEG];
+  float* gw[ZT_MAXSEG];
+  float* gb[ZT_MAXSEG];
+  int nslab[ZT_MAXSEG], ntap[ZT_MAXSEG], CT16[ZT_MAXSEG], NT16[ZT_MAXSEG], Cout[ZT_MAXSEG], Cin[ZT_MAXSEG];
+  int accumulate;
+};
+
+__global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(ReduceTable t) {
+  __shared__ float sh[256];
+  const int sgm = blockIdx.y;
+  const float* __restrict__ slab = t.slab[sgm];
+  const int nslab = t.nslab[sgm], ntap = t.ntap[sgm], CT16 = t.CT16[sgm], NT16 = t.NT16[sgm], Cout = t.Cout[sgm], Cin = t.Cin[sgm];
+  const int ex = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + ex;
+  const int nw = ntap * CT16 * NT16;
+  const int total = nw + NT16;
+  if (blockIdx.x * 32 >= total) return;                         // uniform: this segment is shorter than the longest one
+  float s = 0.f;
+  if (e < total) {
+    const size_t stride = (size_t)total;
+    for (int k = sg; k < nslab; k += 64) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (k + 8 * j < nslab) ? slab[(size_t)(k + 8 * j) * stride + e] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (sg == 0 && e < total) {
+    s = (((sh[ex] + sh[32 + ex]) + (sh[64 + ex] + sh[96 + ex])) + ((sh[128 + ex] + sh[160 + ex]) + (sh[192 + ex] + sh[224 + ex])));
+    if (e < nw) {
+      const int co = e % NT16, ci = (e / NT16) % CT16, tap = e / (NT16 * CT16);
+      if (co < Cout && ci < Cin) {
+        const size_t o = ((size_t)co * Cin + ci) * ntap + tap;
+        t.gw[sgm][o] = t.accumulate ? t.gw[sgm][o] + s : s;
+      }
+    } else if (t.gb[sgm]) {
+      const int co = e - nw;
+      if (co < Cout) t.gb[sgm][co] = t.accumulate ? t.gb[sgm][co] + s : s;
+    }
+  }
+}
+
+// all weight repacks of a step (forward and data-gradient operator of every layer) in one launch: entry = blockIdx.y
+constexpr int ZT_MAXREP = 24;
+struct RepackTable {
+  const float* src[ZT_MAXREP];
+  zt_bf16* dst[ZT_MAXREP];
+  int Cout[ZT_MAXREP], Cin[ZT_MAXREP], K[ZT_MAXREP], CoutP[ZT_MAXREP], ldk[ZT_MAXREP], tflip[ZT_MAXREP];
+};
+
+__global__ void __launch_bounds__(256) repack_w_bf16_multi_kernel(RepackTable t) {
+  const int en = blockIdx.y;
+  const int Cout = t.Cout[en], Cin = t.Cin[en], KH = t.K[en], KW = t.K[en], CoutP = t.CoutP[en], ldk = t.ldk[en];
+  const int total = Cout * Cin * KH * KW;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int kx = idx % KW, ky = (idx / KW) % KH, ci = (idx / (KW * KH)) % Cin, co = idx / (KW * KH * Cin);
+    const zt_bf16 v = zt_f2bf(t.src[en][idx]);
+    if (!t.tflip[en]) t.dst[en][((size_t)(ky * KW + kx) * CoutP + co) * ldk + ci] = v;
+    else t.dst[en][((size_t)((KH - 1 - ky) * KW + (KW - 1 - kx)) * CoutP + ci) * ldk + co] = v;
+  }
+}
+
 template <int KH, int KW>
 int launch_wgrad(const WgradArgs& a, int CT, int NT, int nblk, hipStream_t stream) {
   dim3 grid(nblk), block(256);
@@ -2061,10 +2132,10 @@ extern "C" int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, in
                                      stride, padH, padW, act, alpha, aux, ldaux, epi, 0, stream);
 }
 
-extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout,
-                                         int KH, int KW, float* slab, size_t slab_bytes, float* grad_w, float* grad_b,
-                                         int accumulate, const void* relu_mask, int ldmask, hipStream_t stream) {
-  ZT_REQUIRE(x && dz && slab && grad_w && ldx % 8 == 0 && lddz % 8 == 0);
+// partial pass: every workgroup writes one slab ([tap][ci16][co16] weights + [co16] bias column sums); -> number of slabs
+static int wgrad_partial_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout, int KH, int KW,
+                              float* slab, size_t slab_bytes, const void* relu_mask, int ldmask, int* nslab_out, hipStream_t stream) {
+  ZT_REQUIRE(x && dz && slab && ldx % 8 == 0 && lddz % 8 == 0);
   ZT_REQUIRE(!relu_mask || (ldmask % 8 == 0 && ((uintptr_t)relu_mask & 15) == 0 && KH == 3 && Cin <= 16 && Cout == 64));
   ZT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dz & 15) == 0);
   int CT = (Cin + 15) / 16, NT = (Cout + 15) / 16;
@@ -2075,7 +2146,9 @@ extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
   const bool nw8 = CT == 4 && NT == 4 && !(getenv("ZT_WGRAD_NW4") && atoi(getenv("ZT_WGRAD_NW4")));
   a.ntiles = a.tilesX * zt_cdiv(H, nw8 ? 8 : 4);      // tile rows = waves of the variant (launch_wgrad_h)
   size_t per = ((size_t)KH * KW * CT * 16 * NT * 16 + NT * 16) * sizeof(float);
-  int want = 512;
+  // the 8-wave variant runs one workgroup per CU: 256 slabs keep every CU busy and halve its slab traffic (measured 280 -> 266 us);
+  // the 4-wave variants co-reside two or three per CU
+  int want = nw8 ? 256 : 512;
   if (const char* e = getenv("ZT_WGRAD_BLOCKS")) want = atoi(e) > 0 ? atoi(e) : want;      // tuning hook
   int nblk = a.ntiles < want ? a.ntiles : want;
   if ((size_t)nblk * per > slab_bytes) nblk = (int)(slab_bytes / per);
@@ -2084,9 +2157,71 @@ extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
   if (KH == 3 && KW == 3) rc = launch_wgrad_h<3, 3>(a, CT, NT, nblk, stream);
   else if (KH == 1 && KW == 1) rc = launch_wgrad_h<1, 1>(a, CT, NT, nblk, stream);
   if (rc) return rc;
+  *nslab_out = nblk;
+  return ZT_OK;
+}
+
+extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout,
+                                         int KH, int KW, float* slab, size_t slab_bytes, float* grad_w, float* grad_b,
+                                         int accumulate, const void* relu_mask, int ldmask, hipStream_t stream) {
+  ZT_REQUIRE(grad_w);
+  int nblk = 0;
+  int rc = wgrad_partial_bf16(x, ldx, dz, lddz, H, W, Cin, Cout, KH, KW, slab, slab_bytes, relu_mask, ldmask, &nblk, stream);
+  if (rc) return rc;
+  int CT = (Cin + 15) / 16, NT = (Cout + 15) / 16;
   int total = KH * KW * CT * 16 * NT * 16 + NT * 16;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(zt_cdiv(total, 32)), dim3(256), 0, stream, (const float*)slab, nblk, KH * KW,
                      CT * 16, NT * 16, grad_w, Cout, Cin, accumulate, grad_b);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_conv2d_wgrad_partial_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout, int KH,
+                                            int KW, float* slab, size_t slab_bytes, const void* relu_mask, int ldmask, int* nslab_out,
+                                            hipStream_t stream) {
+  ZT_REQUIRE(nslab_out);
+  int rc = wgrad_partial_bf16(x, ldx, dz, lddz, H, W, Cin, Cout, KH, KW, slab, slab_bytes, relu_mask, ldmask, nslab_out, stream);
+  if (rc) return rc;
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_wgrad_reduce_multi_f32(int nseg, const void* const* slab, const int* nslab, const int* Cin, const int* Cout,
+                                         const int* K, void* const* grad_w, void* const* grad_b, int accumulate, hipStream_t stream) {
+  ZT_REQUIRE(nseg >= 1 && nseg <= ZT_MAXSEG && slab && nslab && Cin && Cout && K && grad_w && grad_b);
+  ReduceTable t;
+  int maxtotal = 0;
+  for (int i = 0; i < ZT_MAXSEG; ++i) {
+    const int j = i < nseg ? i : 0;
+    ZT_REQUIRE(slab[j] && grad_w[j] && nslab[j] >= 1);
+    t.slab[i] = (const float*)slab[j]; t.gw[i] = (float*)grad_w[j]; t.gb[i] = (float*)grad_b[j];
+    t.nslab[i] = nslab[j]; t.ntap[i] = K[j] * K[j]; t.CT16[i] = (Cin[j] + 15) / 16 * 16; t.NT16[i] = (Cout[j] + 15) / 16 * 16;
+    t.Cout[i] = Cout[j]; t.Cin[i] = Cin[j];
+    const int total = t.ntap[i] * t.CT16[i] * t.NT16[i] + t.NT16[i];
+    if (i < nseg && total > maxtotal) maxtotal = total;
+  }
+  t.accumulate = accumulate;
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(zt_cdiv(maxtotal, 32), nseg), dim3(256), 0, stream, t);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_repack_conv_weights_bf16_multi(int n, const void* const* src, void* const* dst, const int* Cout, const int* Cin,
+                                                 const int* K, const int* CoutP, const int* ldk, const int* transpose_flip,
+                                                 hipStream_t stream) {
+  ZT_REQUIRE(n >= 1 && n <= ZT_MAXREP && src && dst && Cout && Cin && K && CoutP && ldk && transpose_flip);
+  RepackTable t;
+  int maxtotal = 0;
+  for (int i = 0; i < ZT_MAXREP; ++i) {
+    const int j = i < n ? i : 0;
+    ZT_REQUIRE(src[j] && dst[j] && CoutP[j] % 16 == 0 && ldk[j] % 8 == 0);
+    t.src[i] = (const float*)src[j]; t.dst[i] = (zt_bf16*)dst[j]; t.Cout[i] = Cout[j]; t.Cin[i] = Cin[j]; t.K[i] = K[j];
+    t.CoutP[i] = CoutP[j]; t.ldk[i] = ldk[j]; t.tflip[i] = transpose_flip[j];
+    const int total = Cout[j] * Cin[j] * K[j] * K[j];
+    if (i < n && total > maxtotal) maxtotal = total;
+  }
+  int gx = zt_cdiv(maxtotal, 256);
+  hipLaunchKernelGGL(repack_w_bf16_multi_kernel, dim3(gx > 64 ? 64 : gx, n), dim3(256), 0, stream, t);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

@@ -33,6 +33,7 @@ class Engine:
         self.dev = device if device is not None else next(iter(params.values())).device
         self.sv = {}
         self.wd = {}
+        self._wg, self._wg_slab = {}, {}
         self.training = True
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -49,6 +50,17 @@ class Engine:
     def repack_weights(self):
         """torch-layout parameters -> device conv layouts (forward and data-gradient operators)."""
         o, p, wd = self.ops, self.p, self.wd
+        layers = (D1 + ".conv1", D1 + ".conv2", D1 + ".conv3", D2 + ".conv1", D2 + ".conv2", D2 + ".conv3",
+                  "enhance.in_conv.0", "enhance.conv.0", "enhance.out_conv.0")
+        if self.dt and all(pre in wd for pre in layers):          # steady state, bf16: every repack of the step in ONE launch
+            ent = []
+            for pre in layers:
+                w = p[pre + ".weight"]
+                ent.append((w, wd[pre], False))
+                if pre + "/T" in wd:
+                    ent.append((w, wd[pre + "/T"], True))
+            o.repack_weights_bf16_multi(ent)
+            return
         rp = o.repack_weight_bf16 if self.dt else o.repack_weight
         for pre in (D1 + ".conv1", D1 + ".conv2", D1 + ".conv3", D2 + ".conv1", D2 + ".conv2", D2 + ".conv3",
                     "enhance.in_conv.0", "enhance.conv.0", "enhance.out_conv.0"):
@@ -64,10 +76,35 @@ class Engine:
             return self.ops.conv2d_bf16(x, self.wd[wkey], bias, cout, k, k, pad, act, out_planar=out_planar, aux=aux, epi=epi)
         return self.ops.conv2d(x, self.wd[wkey], bias, cout, k, k, 1, pad, act, out_planar=out_planar, aux=aux, epi=epi)
 
-    def _wgrad(self, x, dz, cout, k, pre):
-        """accumulate d loss / d weight and d loss / d bias (column sums of dz, same pass) of conv `pre`"""
-        fn = self.ops.conv2d_wgrad_bf16 if self.dt else self.ops.conv2d_wgrad
-        fn(x, dz, cout, k, k, self.g[pre + ".weight"], accumulate=True, grad_b=self.g[pre + ".bias"])
+    def _wgrad(self, x, dz, cout, k, pre, relu_mask=None):
+        """accumulate d loss / d weight and d loss / d bias (column sums of dz, same pass) of conv `pre`.
+        bf16 mode: the call only APPENDS its per-workgroup slabs to the layer's slab region; `_wgrad_flush` reduces every layer
+        of the backward pass in one launch (the three invocations of a shared layer are one longer slab list)."""
+        if not self.dt:
+            self.ops.conv2d_wgrad(x, dz, cout, k, k, self.g[pre + ".weight"], accumulate=True, grad_b=self.g[pre + ".bias"])
+            return
+        o = self.ops
+        xv = x if isinstance(x, CV) else CV(x)
+        per = o.wgrad_slab_floats(xv.C, cout, k)
+        ent = self._wg.get(pre)
+        if ent is None:
+            ent = self._wg[pre] = {"n": 0, "Cin": xv.C, "Cout": cout, "K": k, "per": per}
+        slab = self._wg_slab.get(pre)
+        need = (ent["n"] + 512) * per
+        if slab is None or slab.numel() < need:                   # grows to its steady-state size during the first (eager) steps
+            new = torch.empty(max(need, 3 * 512 * per if slab is None else need), dtype=torch.float32, device=self.dev)
+            if slab is not None and ent["n"]:
+                new[:ent["n"] * per].copy_(slab[:ent["n"] * per])
+            slab = self._wg_slab[pre] = new
+        ent["n"] += o.wgrad_partial_bf16(xv, dz, cout, k, slab, ent["n"] * per, relu_mask=relu_mask)
+
+    def _wgrad_flush(self):
+        if not self._wg:
+            return
+        segs = [(self._wg_slab[pre], e["n"], e["Cin"], e["Cout"], e["K"], self.g[pre + ".weight"], self.g[pre + ".bias"])
+                for pre, e in self._wg.items()]
+        self.ops.wgrad_reduce_multi(segs, accumulate=True)
+        self._wg = {}
 
     def _newa(self, *shape):
         return torch.empty(shape, dtype=self.adt, device=self.dev)
@@ -155,8 +192,7 @@ class Engine:
             df = self._conv(dz, "enhance.conv.0/T", None, 64, 3, None, aux=df, epi=3)
         # through the in_conv ReLU (its input needs no gradient, so only the weight gradient consumes the masked df)
         if self.dt:         # bf16: the mask [feats[0] > 0] is applied while the weight-gradient kernel stages df
-            o.conv2d_wgrad_bf16(CV(u, 0, 9), df, 64, 3, 3, g["enhance.in_conv.0.weight"], accumulate=True,
-                                grad_b=g["enhance.in_conv.0.bias"], relu_mask=feats[0])
+            self._wgrad(CV(u, 0, 9), df, 64, 3, "enhance.in_conv.0", relu_mask=feats[0])
         else:
             dz0 = self._newa(1, H, W, 64)
             self.lib.call("zt_relu_mask_nhwc", df, self.dt, 64, feats[0], 64, dz0, 64, H * W, 64, self._stream())
@@ -329,6 +365,7 @@ class Engine:
         self._denoise_bwd(D1, "D1a", dn11, 3, False)
         self._denoise_bwd(D1, "D1b", dn12, 3, False)
         self._denoise_bwd(D1, "D1c", dn, 3, False)
+        self._wgrad_flush()
         return loss, terms
 
 

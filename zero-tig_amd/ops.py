@@ -423,6 +423,45 @@ class Ops:
         self._ev_end(tok)
         return out
 
+    # ---- deferred, batched weight gradients / weight repacks (bf16 mode) -----------------------------------------------
+    def wgrad_partial_bf16(self, x, dz, Cout, K, slab, slab_off, relu_mask=None):
+        """Append the per-workgroup slabs of one weight-gradient call to `slab` (fp32 tensor) at float offset slab_off.
+        -> number of slabs written."""
+        import ctypes
+        x, dz = _cv(x), _cv(dz)
+        assert x.t.dtype == torch.bfloat16 and dz.t.dtype == torch.bfloat16 and x.N == 1 and (x.H, x.W) == (dz.H, dz.W) and dz.C >= Cout
+        mk = _cv(relu_mask) if relu_mask is not None else None
+        n = ctypes.c_int(0)
+        self.lib.call("zt_conv2d_wgrad_partial_bf16", x.ptr, x.ld, dz.ptr, dz.ld, x.H, x.W, x.C, Cout, K, K, slab.data_ptr() + 4 * slab_off,
+                      (slab.numel() - slab_off) * 4, mk.ptr if mk else None, mk.ld if mk else 0, ctypes.byref(n), self._s(x.t))
+        return n.value
+
+    @staticmethod
+    def wgrad_slab_floats(Cin, Cout, K):
+        c16 = lambda c: (c + 15) // 16 * 16
+        return K * K * c16(Cin) * c16(Cout) + c16(Cout)
+
+    def wgrad_reduce_multi(self, segs, accumulate=True):
+        """segs: [(slab tensor, nslab, Cin, Cout, K, grad_w, grad_b)] -- one launch reduces every layer."""
+        import ctypes
+        n = len(segs)
+        P, I = ctypes.c_void_p * n, ctypes.c_int * n
+        dev = segs[0][0].device
+        self.lib.call("zt_wgrad_reduce_multi_f32", n, P(*[s[0].data_ptr() for s in segs]), I(*[s[1] for s in segs]), I(*[s[2] for s in segs]),
+                      I(*[s[3] for s in segs]), I(*[s[4] for s in segs]), P(*[s[5].data_ptr() for s in segs]),
+                      P(*[(s[6].data_ptr() if s[6] is not None else None) for s in segs]), int(accumulate), current_stream(dev))
+
+    def repack_weights_bf16_multi(self, entries):
+        """entries: [(w fp32 [Cout,Cin,K,K], out bf16 [K*K,CoutP,ldk], transpose_flip)] -- all repacks of a step in one launch."""
+        import ctypes
+        n = len(entries)
+        P, I = ctypes.c_void_p * n, ctypes.c_int * n
+        dev = entries[0][0].device
+        self.lib.call("zt_repack_conv_weights_bf16_multi", n, P(*[e[0].data_ptr() for e in entries]), P(*[e[1].data_ptr() for e in entries]),
+                      I(*[e[0].shape[0] for e in entries]), I(*[e[0].shape[1] for e in entries]), I(*[e[0].shape[2] for e in entries]),
+                      I(*[e[1].shape[1] for e in entries]), I(*[e[1].shape[2] for e in entries]), I(*[int(e[2]) for e in entries]),
+                      current_stream(dev))
+
     def conv3x3_bn_stats_bf16(self, x, wdev, bias, Cout):
         """y = conv3x3(x) + bias (bf16 nhwc) together with the BatchNorm statistics of y: -> (y, partial [1, 512, 2, Cout])."""
         x = _cv(x)
