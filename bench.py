@@ -235,6 +235,16 @@ def main():
         ev = prof["events"].get(name, [])
         return (sum(s.elapsed_time(e) for s, e in ev) / len(ev), len(ev)) if ev else (None, 0)
 
+    # an empty HIP-event pair on the launch stream: what the bracket itself adds to a short kernel's reading
+    pairs = []
+    for _ in range(20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    ev_overhead_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
+
     roof, extra = None, {}
     ms, nl = avg_ms("conv64")
     if ms is not None:
@@ -250,11 +260,13 @@ def main():
                     "launches": nl, "avg_ms": ms, "algorithmic_bytes_per_launch": alg,
                     "mfma_view": {"achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_BF16_MFMA_TFLOPS, "frac": tf / PEAK_BF16_MFMA_TFLOPS,
                                   "algorithmic_flops_per_launch": flops}}
-            try:        # NOT measured in this run: HBM traffic of the same kernel from the committed PMC passes (profiles/)
+            try:        # NOT measured in this run: HBM traffic of the same kernels from the committed PMC passes (profiles/)
                 src = "profiles/r02_pmc_summary.json"
-                pm = json.load(open(os.path.join(ROOT, src)))
-                if (H, W) == (1080, 1920):
-                    roof["traffic_from_profile"] = {"bytes_per_launch": pm["kernels"]["conv_rs_bf16_kernel<2, 2, true, 2, 0>"]["hbm_bytes_per_launch_avg"],
+                pm = json.load(open(os.path.join(ROOT, src)))["kernels"]
+                ks = [v for k, v in pm.items() if k.startswith("conv_rs_bf16_kernel<2, 2, true, 2, 0,")]
+                if (H, W) == (1080, 1920) and ks:
+                    nd = sum(v["dispatches"] for v in ks)
+                    roof["traffic_from_profile"] = {"bytes_per_launch": sum(v["hbm_bytes_per_launch_avg"] * v["dispatches"] for v in ks) / nd,
                                                     "source": src}
             except Exception:
                 pass
@@ -267,13 +279,13 @@ def main():
         alg = 4 * px * 3 * 4 + (H // a.of_scale) * (W // a.of_scale) * 2 * 4.0
         extra["warp2_kernel"] = {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_ms": ms, "launches": nl,
-                                 "algorithmic_bytes_per_launch": alg}
+                                 "algorithmic_bytes_per_launch": alg, "event_pair_overhead_ms": ev_overhead_ms}
     ms, nl = avg_ms("corr")
     if ms is not None:          # corr.py:52-60: the fp32 all-pairs volume written once (+ both feature maps read)
         alg = float(npx) * npx * 4 + 2 * npx * 256 * (2 if a.precision == "bf16" else 4)
         extra["corr_volume"] = {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_ms": ms, "launches": nl,
-                                "algorithmic_bytes_per_launch": alg}
+                                "algorithmic_bytes_per_launch": alg, "event_pair_overhead_ms": ev_overhead_ms}
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_baseline != "none":
