@@ -298,3 +298,46 @@ def test_bf16_training_trajectory_tracks_fp32(hip_ops, synth, oracle):
         assert abs(x - y) <= 2e-2 * abs(x), (traj["fp32"], traj["bf16"])
     clean = torch.from_numpy(synth.clean_frame(steps - 1, H, W)).float()[None]
     assert abs(oracle.psnr_u8(nets["fp32"].last_H3.cpu(), clean) - oracle.psnr_u8(nets["bf16"].last_H3.cpu(), clean)) <= 0.01
+
+
+def test_scripts_train_resume_predict_pipeline(tmp_path, synth):
+    """the reference's scripts end to end on a tiny BVI-RLV-layout clip (the loader resizes to 1920 x 1080): train.py
+    (hipGraph stepper, per-epoch weights + resume file + result PNGs), resume, predict.py, and run_pipeline.py -> evals.py
+    (device PSNR, Metrics.json)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = tmp_path / "data" / "RLV"
+    for kind, sub, fn in (("input", "low_light_10", synth.lowlight_frame), ("gt", "normal_light_10", synth.clean_frame)):
+        d = data / kind / "S01" / sub
+        d.mkdir(parents=True)
+        for t in range(4):
+            im = (np.transpose(fn(t, 270, 480), (1, 2, 0)) * 255.0 + 0.5).astype(np.uint8)
+            Image.fromarray(im).save(str(d / ("%05d.png" % (t + 1))))
+    (data / "train_list.txt").write_text("S01\n")
+    (data / "test_list.txt").write_text("S01\n")
+    env = dict(os.environ, PYTHONPATH=root)
+
+    def run(*cmd):
+        r = subprocess.run([sys.executable] + list(cmd), cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (cmd, r.stdout[-3000:], r.stderr[-3000:])
+        return r.stdout
+    exp = tmp_path / "exp"
+    out = run("run_pipeline.py", "--datasets", "RLV", "--base_data_dir", str(tmp_path / "data"), "--base_exp_dir", str(exp), "--epochs", "2",
+              "--weights_dir", str(tmp_path / "none"))
+    tr = [d for d in (exp / "RLV" / "training").iterdir() if d.name.startswith("Train-")][0]
+    for f in ("initial_weights.pt", "model_epochs/weights_0.pt", "model_epochs/weights_1.pt", "model_epochs/resume.pt", "log.txt"):
+        assert (tr / f).exists(), f
+    assert len(list((tr / "result" / "denoise").glob("*.png"))) == 8          # 4 test frames x 2 epochs
+    m = json.load(open(exp / "RLV" / "evaluation" / "Metrics.json"))
+    assert m["images"] == 4 and 3.0 < m["Total_PSNR"] < 60.0
+    ck = torch.load(str(tr / "model_epochs" / "resume.pt"))
+    assert ck["epoch"] == 2 and ck["step"] == 8 and len(ck["model"]) == 223 and ck["optimizer"]["t"] == 8
+    out = run("train.py", "--lowlight_images_path", str(data), "--save", str(tmp_path / "exp2"), "--epochs", "3", "--resume",
+              str(tr / "model_epochs" / "resume.pt"))
+    assert "resumed from" in out and "train-epoch 002" in out and "train-epoch 000 " not in out
+    run("predict.py", "--lowlight_images_path", str(data), "--save", str(tmp_path / "pred"), "--model_pretrain", str(tr / "model_epochs" / "weights_1.pt"))
+    assert len(list((tmp_path / "pred").rglob("*_denoise.png"))) == 4 and len(list((tmp_path / "pred").rglob("*_enhance.png"))) == 4

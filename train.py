@@ -36,6 +36,7 @@ parser.add_argument("--of_scale", type=int, default=3, help="downscale factor fo
 parser.add_argument("--dataset", type=str, default="RLV", help="dataset name")
 parser.add_argument("--num_workers", type=int, default=0, help="dataloader workers")
 parser.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"], help="bf16 throughput mode / fp32 parity mode")
+parser.add_argument("--graph", type=int, default=1, help="1: replay the steady-state step from a captured hipGraph (zero-tig_amd/optim.py:TrainStep); 0: eager launches")
 parser.add_argument("--resume", type=str, default=None, help="resume file written every epoch (model + Adam moments + step + loop position)")
 parser.add_argument("--reference_eval_quirk", action="store_true", help="stay in eval() after the first epoch like the reference (train.py:138)")
 
@@ -105,6 +106,7 @@ def main():
                                               num_workers=args.num_workers, shuffle=False)
     test_queue = torch.utils.data.DataLoader(test_set, batch_size=1, pin_memory=True, num_workers=args.num_workers, shuffle=False)
 
+    stepper = optim.TrainStep(model, optimizer, use_graph=bool(args.graph))
     total_step, first_epoch = 0, 0
     if args.resume:
         first_epoch, total_step = utils.load_checkpoint(model, optimizer, args.resume)
@@ -115,13 +117,10 @@ def main():
         for it, (inp, img_name, img_path, last_img_path) in enumerate(train_queue):
             if it >= steps_per_epoch:
                 break
-            model.is_new_seq = it == 0 or utils.sequential_judgment(img_path[0], last_img_path[0])
+            new_seq = it == 0 or utils.sequential_judgment(img_path[0], last_img_path[0])
             total_step += 1
-            inp = inp.to(dev, non_blocking=True)
-            optimizer.zero_grad()
-            loss = model._loss(inp)
-            loss.backward()
-            optimizer.step()                    # clip_grad_norm_(5) + Adam fused; all-reduce first when world > 1
+            # zero_grad + _loss + backward + (all-reduce) + clip_grad_norm_(5) + Adam (train.py:126-131); pinned frame -> HBM inside
+            loss = stepper(inp, is_new_seq=new_seq)
             losses.append(loss.item())
             logging.info("train-epoch %03d %03d %f", epoch, it, losses[-1])
         logging.info("train-epoch %03d %f", epoch, np.average(losses))

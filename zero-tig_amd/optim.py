@@ -124,7 +124,7 @@ class TrainStep:
 
     def __init__(self, model, optimizer, use_graph=True):
         self.model, self.opt, self.use_graph = model, optimizer, use_graph
-        self.graph, self.x, self.loss, self.n_eager_steady = None, None, None, 0
+        self.graph, self.x, self.loss, self.n_eager_steady, self._mode = None, None, None, 0, None
 
     def _body(self, x):
         """zero_grad + loss + gradients straight into the optimizer's flat bucket (no autograd bookkeeping, no ATen math)"""
@@ -143,6 +143,12 @@ class TrainStep:
                 loss = self._body(frame.to(dev, non_blocking=True))
             self.opt.step()
             return loss
+        if self.graph is not None and (self._mode != m.training or tuple(self.x.shape) != tuple(frame.shape)):
+            # BatchNorm mode (the reference trains epochs >= 1 in eval mode, train.py:138) or the frame size changed: the captured
+            # launch sequence no longer applies -> capture again after one eager step
+            self.graph, self.n_eager_steady = None, 0
+            if tuple(self.x.shape) != tuple(frame.shape):
+                self.x = None
         if self.x is None:
             self.x = torch.empty(frame.shape, dtype=torch.float32, device=dev)
             m.enable_static_cache(frame.shape)
@@ -161,7 +167,7 @@ class TrainStep:
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.loss = self._body(self.x)
-            self.graph = g
+            self.graph, self._mode = g, m.training
         self.graph.replay()
         self.opt.step()
         return self.loss
