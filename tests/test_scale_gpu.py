@@ -315,7 +315,8 @@ def test_scripts_train_resume_predict_pipeline(tmp_path, synth):
         d = data / kind / "S01" / sub
         d.mkdir(parents=True)
         for t in range(4):
-            im = (np.transpose(fn(t, 270, 480), (1, 2, 0)) * 255.0 + 0.5).astype(np.uint8)
+            a = np.asarray(fn(t, 270, 480), dtype=np.float32)
+            im = (np.transpose(a[0] if a.ndim == 4 else a, (1, 2, 0)) * 255.0 + 0.5).astype(np.uint8)
             Image.fromarray(im).save(str(d / ("%05d.png" % (t + 1))))
     (data / "train_list.txt").write_text("S01\n")
     (data / "test_list.txt").write_text("S01\n")
