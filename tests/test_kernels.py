@@ -606,3 +606,24 @@ def test_conv3x3_bn_stats_bf16(backend, force_fused, monkeypatch):
     sc, sh, mean, rstd = ops.norm_finalize(part, 1, 64, H * W, 0)
     assert maxerr(mean, got.mean(dim=(0, 2, 3)).view(1, 64)) < 1e-5
     assert maxerr(rstd, 1.0 / torch.sqrt(got.double().var(dim=(0, 2, 3), unbiased=False) + 1e-5).view(1, 64)) < 1e-4
+
+
+@pytest.mark.parametrize("cin,with_bias", [(3, False), (6, False), (6, True)], ids=["c3-plain", "c6-plain", "c6-generic"])
+def test_conv1x1_thin_input_bf16(backend, cin, with_bias):
+    """Data gradient of Denoise_1/2's 1x1 output layer (3/6 -> 48 channels, LeakyReLU-mask epilogue): the streaming thin-input
+    kernel, specialised (no bias / activation) and generic form, vs torch on the bf16-rounded operands."""
+    import torch.nn.functional as F
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    g = torch.Generator().manual_seed(cin)
+    H, W = 13, 29
+    x = torch.randn(1, cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(48, cin, 1, 1, generator=g) / cin ** 0.5)
+    b = torch.randn(48, generator=g) * 0.1 if with_bias else None
+    aux = torch.randn(1, 48, H, W, generator=g).bfloat16().float()
+    ref = F.conv2d(x, w.bfloat16().float(), b) * torch.where(aux > 0, 1.0, 0.2)
+    y = ops.conv2d_bf16(CV(_nhwc_bf16(x, 8).to(dev), 0, cin), ops.repack_weight_bf16(w.to(dev)), b.to(dev) if with_bias else None, 48, 1, 1,
+                        (0, 0), None, aux=_nhwc_bf16(aux, 48).to(dev), epi=1)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert float(((got - ref).abs() - ref.abs() * 2 ** -8).max()) < 2e-3

@@ -1058,17 +1058,29 @@ int launch_conv_ws(ConvArgsH& a, int NT, int CCH, int pth, hipStream_t stream) {
 // ---- 1x1 convolution with a thin input (Cin <= 8: the data gradient of Denoise_1/2's 48 -> 3 / 48 -> 6 output layers).
 // 2 * Cin FLOP per output element: a pure streaming kernel, no MFMA.  Thread = one cout octet x 4 pixels (weights for its 8
 // couts live in registers); load j of a wave covers 64 / (Cout/8) consecutive pixels; 16-byte loads and stores throughout.
+// PLAIN: the path's only use (data gradient of Denoise_1/2's 1x1 output layer: no bias, no activation, alpha 1, LeakyReLU-mask
+// epilogue) with 48 couts -- compile-time octet count (the 64-bit i % Q8, i / Q8 and the per-element runtime epilogue selection
+// made the generic form issue-bound: ~1600 instructions per thread for 32 outputs, 3.1 TB/s)
+template <bool PLAIN>
 __global__ void __launch_bounds__(256) conv1x1_thin_bf16_kernel(ConvArgsH a, int npg) {
-  const int Q8 = a.Cout >> 3;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int o = (int)(i % Q8), pg = (int)(i / Q8);
+  const int Q8 = PLAIN ? 6 : (a.Cout >> 3);
+  int o, pg;
+  if constexpr (PLAIN) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    o = (int)(i % 6u);
+    pg = (int)(i / 6u);
+  } else {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    o = (int)(i % Q8);
+    pg = (int)(i / Q8);
+  }
   if (pg >= npg) return;
   const int HW = a.Ho * a.Wo;
   float w[8][8], b[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     zt_ld8(a.w + (size_t)(o * 8 + c) * a.ldk, w[c]);            // [CoutP][ldk = 8], zero beyond Cin
-    b[c] = a.bias ? a.bias[o * 8 + c] : 0.f;
+    b[c] = (!PLAIN && a.bias) ? a.bias[o * 8 + c] : 0.f;
   }
   const float slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.2f);
   const float neg = a.epi == 1 ? 0.2f : 0.f;
@@ -1077,7 +1089,7 @@ __global__ void __launch_bounds__(256) conv1x1_thin_bf16_kernel(ConvArgsH a, int
   for (int j = 0; j < 4; ++j) {
     const int p = min(pg + j * npg, HW - 1);
     zt_ld8(a.x + (size_t)p * a.ldx, x[j]);
-    if (a.epi) zt_ld8(a.aux + (size_t)p * a.ldaux + o * 8, u[j]);
+    if (PLAIN || a.epi) zt_ld8(a.aux + (size_t)p * a.ldaux + o * 8, u[j]);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j)                                   // the buffer's padding lanes are not trusted (NaN * 0)
@@ -1092,10 +1104,14 @@ __global__ void __launch_bounds__(256) conv1x1_thin_bf16_kernel(ConvArgsH a, int
       float s = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) s = fmaf(w[c][k], x[j][k], s);
-      s = a.alpha * (s + b[c]);
-      s = fmaxf(s, slope * s);
-      if (a.epi == 3) s += u[j][c];
-      else if (a.epi) s *= (u[j][c] > 0.f ? 1.f : neg);
+      if constexpr (PLAIN) {
+        s *= (u[j][c] > 0.f ? 1.f : 0.2f);
+      } else {
+        s = a.alpha * (s + b[c]);
+        s = fmaxf(s, slope * s);
+        if (a.epi == 3) s += u[j][c];
+        else if (a.epi) s *= (u[j][c] > 0.f ? 1.f : neg);
+      }
       r[c] = s;
     }
     if (p < HW) zt_st8((zt_bf16*)a.y + (size_t)p * a.ldy + o * 8, r);
@@ -2046,7 +2062,11 @@ static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, 
       out_mode == 0 && act <= 2 && Cout % 8 == 0 && CoutP >= Cout && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
       (!aux || (ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0))) {
     const int npg = zt_cdiv(a.Ho * a.Wo, 4);
-    hipLaunchKernelGGL(conv1x1_thin_bf16_kernel, dim3((unsigned)zt_cdivl((long long)npg * (Cout / 8), 256)), dim3(256), 0, stream, a, npg);
+    const dim3 g1((unsigned)zt_cdivl((long long)npg * (Cout / 8), 256));
+    if (Cout == 48 && !bias && act == 0 && alpha == 1.f && epi == 1 && (long long)npg * 6 < 0x7FFFFFFFll)
+      hipLaunchKernelGGL(conv1x1_thin_bf16_kernel<true>, g1, dim3(256), 0, stream, a, npg);
+    else
+      hipLaunchKernelGGL(conv1x1_thin_bf16_kernel<false>, g1, dim3(256), 0, stream, a, npg);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
   }

@@ -8,8 +8,36 @@
 namespace {
 
 // ---- per-channel sums of a planar tensor: partial[blk][c]
+// All C <= 4 planes of a block's pixel range in one sweep, 16-byte loads, eight independent loads in flight per thread and plane
+// (the one-plane-at-a-time scalar loop with a block reduction per plane read 25 MB in 44 us).
 __global__ void __launch_bounds__(256) plane_sums_kernel(const float* __restrict__ x, int C, long long HW, int nblk,
                                                          float* __restrict__ partial) {
+  __shared__ float red[16 * 4];
+  long long chunk = ((HW + nblk - 1) / nblk + 3) & ~3ll;         // multiple of 4: 16-byte aligned block ranges (HW % 4 == 0 checked by the host)
+  const long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk < HW ? p0 + chunk : HW;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long long p = p0 + 4 * threadIdx.x; p < p1; p += 8 * 1024) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < C) {
+        float4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const long long q = p + j * 1024;
+          t[j] = *reinterpret_cast<const float4*>(x + (size_t)c * HW + (q < p1 ? q : p0));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[c] += (p + j * 1024 < p1) ? ((t[j].x + t[j].y) + (t[j].z + t[j].w)) : 0.f;
+      }
+    }
+  }
+  zt_block_sum<4>(v, red);
+  if (threadIdx.x == 0)
+    for (int c = 0; c < C; ++c) partial[blockIdx.x * C + c] = v[c];
+}
+
+__global__ void __launch_bounds__(256) plane_sums_scalar_kernel(const float* __restrict__ x, int C, long long HW, int nblk,
+                                                                float* __restrict__ partial) {
   __shared__ float red[16 * 4];
   long long chunk = (HW + nblk - 1) / nblk;
   long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk < HW ? p0 + chunk : HW;
@@ -256,7 +284,8 @@ __global__ void __launch_bounds__(256) loss_full_kernel(const float* __restrict_
 
 extern "C" int zt_plane_sums_f32(const float* x, int C, long long HW, int nblk, float* partial, hipStream_t stream) {
   ZT_REQUIRE(x && partial && nblk > 0);
-  hipLaunchKernelGGL(plane_sums_kernel, dim3(nblk), dim3(256), 0, stream, x, C, HW, nblk, partial);
+  if (C <= 4 && HW % 4 == 0 && ((uintptr_t)x & 15) == 0) hipLaunchKernelGGL(plane_sums_kernel, dim3(nblk), dim3(256), 0, stream, x, C, HW, nblk, partial);
+  else hipLaunchKernelGGL(plane_sums_scalar_kernel, dim3(nblk), dim3(256), 0, stream, x, C, HW, nblk, partial);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }
