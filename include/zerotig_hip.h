@@ -192,6 +192,14 @@ int zt_clip_adam_f32(float* p, const float* g, float* m, float* v, long long n, 
 int zt_axpy_dev_f32(float* y, const float* x, const float* alpha, long long n, zt_stream_t stream);
 
 
+/* ---- RAFT encoder stem in bf16 mode (zt_stem.hip): conv 7x7 / stride 2 / pad 3, 3 -> 64 (extractor.py:120, 168-170).
+ * x: nhwc [N][H][W][8] bf16, channels 0..2 valid and 3..7 ZERO (as zt_raft_pack_input / zt_raft_pack_pair write them);
+ * w: zt_repack_stem_weight_bf16 of the torch weight [64][3][7][7] -> [7][64][64] bf16; y: nhwc [N][H/2][W/2][ldy >= 64] bf16
+ * = conv + bias (the norm / ReLU that follow are separate, as in the generic path). */
+int zt_repack_stem_weight_bf16(const float* src, void* dst, zt_stream_t stream);
+int zt_raft_stem_conv_bf16(const void* x, int N, int H, int W, const void* w, const float* bias, void* y, int ldy, zt_stream_t stream);
+
+
 /* ---- output side (zt_io.hip): predict.py:57-61 save_images and evals.py:83-85 PSNR on the device -------------------------
  * zt_quantize_u8_hwc: planar fp32 [3][H][W] in [0,1] -> interleaved uint8 [H][W][3] (what PIL / cv2 write);
  *   mode 0 = clip(x*255, 0, 255) truncated (predict.py / train.py save_images), mode 1 = np.round(x*255) (evals.py:83-84).

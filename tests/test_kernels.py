@@ -627,3 +627,21 @@ def test_conv1x1_thin_input_bf16(backend, cin, with_bias):
                         (0, 0), None, aux=_nhwc_bf16(aux, 48).to(dev), epi=1)
     got = y.float().cpu().permute(0, 3, 1, 2)
     assert float(((got - ref).abs() - ref.abs() * 2 ** -8).max()) < 2e-3
+
+
+def test_raft_stem_conv_bf16(backend):
+    """RAFT encoder stem (extractor.py:120): the dedicated bf16 kernel (7 px x 8 ch per kernel row as one K range) vs torch
+    conv2d(stride 2, padding 3) on the bf16-rounded operands; 2 images, ragged tiles on both axes."""
+    import torch.nn.functional as F
+    ops, dev, _ = backend
+    g = torch.Generator().manual_seed(21)
+    N, H, W = 2, 22, 76
+    x = torch.randn(N, 3, H, W, generator=g).bfloat16().float()
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12.0
+    b = torch.randn(64, generator=g) * 0.1
+    ref = F.conv2d(x, w.bfloat16().float(), b, stride=2, padding=3)
+    xd = _nhwc_bf16(x, 8).to(dev)
+    y = ops.raft_stem_bf16(xd, ops.raft_stem_weight_bf16(w.to(dev)), b.to(dev))
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    assert float(((got - ref).abs() - ref.abs() * 2 ** -8).max()) < 2e-3

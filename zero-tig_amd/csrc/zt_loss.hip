@@ -70,8 +70,11 @@ __global__ void loss_scalars_kernel(const float* __restrict__ partial, int nblk,
   }
 }
 
-__constant__ int c_off_dy[12] = {1, 0, 1, 1, 2, 0, 2, 2, 1, 1, 2, 2};
-__constant__ int c_off_dx[12] = {0, 1, 1, -1, 0, 2, 1, -1, 2, -2, 2, -2};
+constexpr int k_off_dy[12] = {1, 0, 1, 1, 2, 0, 2, 2, 1, 1, 2, 2};
+constexpr int k_off_dx[12] = {0, 1, 1, -1, 0, 2, 1, -1, 2, -2, 2, -2};
+struct SmoothCoef {
+  float coef[12];
+};
 
 // Terms 0-3 (loss.py:46-49) and their direct gradient w.r.t. s2.  L2 is detached in all four.
 // A workgroup owns a 64 x 16 tile; the s2 and Y planes of the tile plus the +-2 halo that the 24 shifted differences of
@@ -82,7 +85,7 @@ constexpr int LS_TX = 64, LS_TY = 16, LS_HALO = 2, LS_PW = LS_TX + 2 * LS_HALO, 
 
 __global__ void __launch_bounds__(256) loss_s2_kernel(const float* __restrict__ L2, const float* __restrict__ s2,
                                                       const float* __restrict__ Y, const float* __restrict__ scal, int H,
-                                                      int W, float* __restrict__ ds2, float* __restrict__ partial, int nrow4) {
+                                                      int W, float* __restrict__ ds2, float* __restrict__ partial, int nrow4, SmoothCoef sc) {
   __shared__ float red[16 * 4];
   __shared__ float sS[3][LS_PH][LS_PW];
   __shared__ float sY[3][LS_PH][LS_PW];
@@ -138,16 +141,18 @@ __global__ void __launch_bounds__(256) loss_s2_kernel(const float* __restrict__ 
         }
         if (x >= 1) g[c] += 2.f * (sq[c] - sS[c][ly][lx - 1]) * cw;
       }
-      // bilateral smoothness (loss.py:173-311): 12 offsets, each counted twice, weight 5
-      for (int k = 0; k < 12; ++k) {
-        const int dy = c_off_dy[k], dx = c_off_dx[k];
-        const int adx = dx < 0 ? -dx : dx;
-        const float coef = 10.f / ((float)(H - dy) * (float)(W - adx));
+      // bilateral smoothness (loss.py:173-311): 12 offsets, each counted twice, weight 5.  Offsets are compile-time constants
+      // (immediate LDS offsets, no index arithmetic) and the per-offset normalisation 10 / ((H - dy)(W - |dx|)) arrives
+      // precomputed: the kernel is bound by vector-instruction issue (24 exp + ~150 neighbour operations per pixel), not memory.
+      zt_static_for<0, 12>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int dy = k_off_dy[k], dx = k_off_dx[k];
+        const float coef = sc.coef[k];
         // pair (q, q+d)
-        int yy = y + dy, xx = x + dx;
-        if (yy < H && xx >= 0 && xx < W) {
+        if (y + dy < H && x + dx >= 0 && x + dx < W) {
           float e = 0.f, a = 0.f;
           float sg[3];
+#pragma unroll
           for (int c = 0; c < 3; ++c) {
             float dyv = yq[c] - sY[c][ly + dy][lx + dx];
             e += dyv * dyv;
@@ -157,14 +162,14 @@ __global__ void __launch_bounds__(256) loss_s2_kernel(const float* __restrict__ 
           }
           float wgt = expf(e * -0.005f) * coef;
           t[2] += wgt * a;
+#pragma unroll
           for (int c = 0; c < 3; ++c) g[c] += wgt * sg[c];
         }
         // pair (q-d, q): gradient only (the forward term belongs to pixel q-d)
-        yy = y - dy;
-        xx = x - dx;
-        if (yy >= 0 && xx >= 0 && xx < W) {
+        if (y - dy >= 0 && x - dx >= 0 && x - dx < W) {
           float e = 0.f;
           float sg[3];
+#pragma unroll
           for (int c = 0; c < 3; ++c) {
             float dyv = sY[c][ly - dy][lx - dx] - yq[c];
             e += dyv * dyv;
@@ -172,9 +177,10 @@ __global__ void __launch_bounds__(256) loss_s2_kernel(const float* __restrict__ 
             sg[c] = ds > 0.f ? 1.f : (ds < 0.f ? -1.f : 0.f);
           }
           float wgt = expf(e * -0.005f) * coef;
+#pragma unroll
           for (int c = 0; c < 3; ++c) g[c] += wgt * sg[c];
         }
-      }
+      });
       for (int c = 0; c < 3; ++c) ds2[c * HW + o] = g[c];
     }
   }
@@ -300,8 +306,13 @@ extern "C" int zt_loss_scalars_f32(const float* partial, int nblk, long long HW,
 extern "C" int zt_loss_s2_f32(const float* L2, const float* s2, const float* Y, const float* scal, int H, int W, float* ds2,
                               float* partial, hipStream_t stream) {
   ZT_REQUIRE(L2 && s2 && Y && scal && ds2 && partial && H > 2 && W > 2);
+  SmoothCoef sc;
+  for (int k = 0; k < 12; ++k) {
+    const int adx = k_off_dx[k] < 0 ? -k_off_dx[k] : k_off_dx[k];
+    sc.coef[k] = 10.f / ((float)(H - k_off_dy[k]) * (float)(W - adx));      // same fp32 expression the kernel used to evaluate per pixel
+  }
   hipLaunchKernelGGL(loss_s2_kernel, dim3(zt_cdiv(W, LS_TX), zt_cdiv(H, LS_TY)), dim3(64, 4), 0, stream, L2, s2, Y, scal, H, W, ds2, partial,
-                     zt_cdiv(H, 4));
+                     zt_cdiv(H, 4), sc);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

@@ -339,6 +339,22 @@ class Ops:
         self.lib.call("zt_raft_pack_input", img1, q2, lut, out, _dt(out), ld, h, w, Hp, Wp, self._s(img1))
         return out
 
+    def raft_stem_weight_bf16(self, w):
+        """torch [64,3,7,7] fp32 -> [7,64,64] bf16 (k = kx*8 + c) for raft_stem_bf16"""
+        _f32c(w)
+        assert tuple(w.shape) == (64, 3, 7, 7)
+        out = torch.empty((7, 64, 64), dtype=torch.bfloat16, device=w.device)
+        self.lib.call("zt_repack_stem_weight_bf16", w, out, self._s(w))
+        return out
+
+    def raft_stem_bf16(self, x, wstem, bias):
+        """x: nhwc [N,H,W,8] bf16 (channels 3..7 zero) -> conv7x7 s2 p3 + bias: nhwc [N,H/2,W/2,64] bf16 (extractor.py:120)"""
+        assert x.dtype == torch.bfloat16 and x.shape[-1] == 8 and x.is_contiguous()
+        N, H, W, _ = x.shape
+        out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), dtype=torch.bfloat16, device=x.device)
+        self.lib.call("zt_raft_stem_conv_bf16", x, N, H, W, wstem, bias, out, 64, self._s(x))
+        return out
+
     def corr_pyramid(self, corr0, h, w):
         """corr0: NHWC [1,h,w,ld>=h*w] level 0 -> [level1, level2, level3] tensors [npx, hl, wl]."""
         npx, ld = h * w, corr0.shape[-1]

@@ -77,6 +77,10 @@ class RaftPlan:
             if ".gru.conv" in name:
                 continue
             self.wd[name] = rp(v.contiguous())
+        self.wstem = {}
+        if self.h:
+            for enc in ("fnet", "cnet"):
+                self.wstem[enc] = o.raft_stem_weight_bf16(self._w(enc + ".conv1.weight").contiguous())
         g = "update_block.gru."
         for sfx in ("1", "2"):
             wz, wr = self._w(g + "convz" + sfx + ".weight"), self._w(g + "convr" + sfx + ".weight")
@@ -140,7 +144,10 @@ class RaftPlan:
 
     def _encoder(self, enc, x, kind):
         """extractor.py:117-191 up to (not including) the 1x1 output conv."""
-        y = self._conv(CV(x, 0, 3), enc + ".conv1", 64, 7, 2)
+        if self.h and x.shape[-1] == 8:       # bf16 mode: dedicated stem kernel (7 px x 8 ch of a kernel row = one 64-wide K range)
+            y = self.ops.raft_stem_bf16(x, self.wstem[enc], self._w(enc + ".conv1.bias"))
+        else:
+            y = self._conv(CV(x, 0, 3), enc + ".conv1", 64, 7, 2)
         y = self._norm(y, enc + ".norm1", kind, True)
         for li, dim, stride in ((1, 64, 1), (2, 96, 2), (3, 128, 2)):
             y = self._res_block("%s.layer%d.0" % (enc, li), y, dim, stride, kind)
