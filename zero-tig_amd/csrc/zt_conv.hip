@@ -2040,7 +2040,10 @@ static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, 
   long long wgs = (long long)zt_cdiv(a.Wo, 32) * a.tilesY * N * zt_cdiv(c16, NT);
   if (wgs < 512 || stride == 2) MT = 1;
   if (MT == 1 && NT == 4 && (long long)zt_cdiv(a.Wo, 16) * a.tilesY * N * zt_cdiv(c16, NT) < 512 && c16 % 2 == 0) NT = 2;
-  if (wgs < 512 && stride == 1) {                               // tuning hooks for the small-map tile shape (tools/bench_small.py)
+  // 32 couts per workgroup keep every tap's weights of a chunk resident next to the pixel tile (one staging + two barriers per chunk
+  // instead of one per kernel row): -65 us over the RAFT encoders' 64-channel 180 x 320 layers (tools/bench_raft.py)
+  if (NT == 4 && c16 % 2 == 0 && stride == 1) NT = 2;
+  if (stride == 1) {                                            // tuning hooks for the tile shape (tools/bench_small.py, bench_raft.py)
     static const int fmt = getenv("ZT_TILED_MT") ? atoi(getenv("ZT_TILED_MT")) : 0, fnt = getenv("ZT_TILED_NT") ? atoi(getenv("ZT_TILED_NT")) : 0;
     if (fmt == 1 || fmt == 2) MT = fmt;
     if (fnt >= 1 && fnt <= 4 && c16 % fnt == 0) NT = fnt;
