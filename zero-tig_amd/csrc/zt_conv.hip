@@ -508,8 +508,10 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
   constexpr int IR = (TH - 1) * S + KH, IC = (TWm - 1) * S + KW;
   constexpr int TG = ALL ? KH * KW : KW;          // taps staged together
   constexpr int NG = ALL ? 1 : KH;
-  __shared__ __attribute__((aligned(16))) zt_bf16 xs[IR * IC * KCHP];
-  __shared__ __attribute__((aligned(16))) zt_bf16 ws[TG * NT * 16 * KCHP];
+  constexpr int XS_ELEMS = IR * IC * KCHP, WS_ELEMS = TG * NT * 16 * KCHP;      // XS_ELEMS * 2 bytes is a multiple of 16 (KCHP is)
+  __shared__ __attribute__((aligned(16))) zt_bf16 smem[XS_ELEMS + WS_ELEMS];    // pixel tile | weight tile; the fp32 epilogue re-uses both
+  zt_bf16* const xs = smem;
+  zt_bf16* const ws = smem + XS_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // grid = (tile columns, cout groups, tile rows x images): no integer divisions in the (issue-bound) prologue
@@ -717,6 +719,42 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
   }
 
   const int oy = oy0 + wave;
+  // fp32 nhwc output without a fused operand (the all-pairs correlation volume, corr.py:52-60: 52 MB at 1080p): the accumulator
+  // layout gives every lane 4-byte stores 64 bytes apart; transposed through LDS each lane writes 16 contiguous bytes of a
+  // pixel's cout run instead.  Wave-private slice of the (now idle) pixel / weight staging buffers.
+  constexpr int SP = NT * 16 + 4;                               // staging row pitch in floats
+  constexpr bool CAN_STAGE = 4 * 16 * MT * SP * 4 <= (XS_ELEMS + WS_ELEMS) * 2;
+  if constexpr (CAN_STAGE) {
+    if (a.out_mode == 2 && a.epi == 0 && a.ldy % 4 == 0 && !(a.dbg & 2)) {      // uniform
+      __syncthreads();                                          // every wave is done with the operand tiles
+      float* stg = reinterpret_cast<float*>(smem) + wave * (16 * MT * SP);
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            stg[(m * 16 + l4 * 4 + j) * SP + q * 16 + l15] = apply_act_fast(a.alpha * (acc[m][q][j] + bias_q[q]), a.act);
+      __builtin_amdgcn_wave_barrier();                          // same wave writes and reads (LDS ops of a wave complete in order)
+      if (oy < a.Ho) {
+        constexpr int C4 = NT * 4;                              // 16-byte chunks per pixel
+        for (int e = lane; e < 16 * MT * C4; e += 64) {
+          const int p = e / C4, c4 = e - p * C4;
+          const int ox = ox0 + p, co = co0 + c4 * 4;
+          if (ox < a.Wo && co < a.Cout) {
+            const float4 v = *reinterpret_cast<const float4*>(stg + p * SP + c4 * 4);
+            float* dst = (float*)a.y + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.ldy + co;
+            if (co + 4 <= a.Cout) *reinterpret_cast<float4*>(dst) = v;
+            else {
+              const float t[4] = {v.x, v.y, v.z, v.w};
+              for (int k = 0; k < 4 && co + k < a.Cout; ++k) dst[k] = t[k];
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
   if (oy >= a.Ho) return;
   if (a.dbg & 2) {                                              // ablation: no epilogue (accumulators kept live)
     if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[MT - 1][NT - 1][3];

@@ -238,7 +238,9 @@ class Engine:
         lib.call("zt_clamp_sub6_f32", H12, s22, r4, H4p, H4p[:, 3:], h * w, s)
         lib.call("zt_clamp_sub6_f32", H2, s2, r5, H5p, H5p[:, 3:], H * W, s)
         H3, s3 = H5p[:, :3], H5p[:, 3:]
-        m_l = o.texture_mask(Lp1, Lp2)
+        # L_pred1_L_pred2_diff (model.py:194) is returned by forward() but never reaches the loss (loss.py ignores it): the
+        # training plan (keep) does not compute it
+        m_l = None if keep else o.texture_mask(Lp1, Lp2)
         H3d1, H3d2 = o.pair_down(H3)
         m_h = o.texture_mask(H3d1, H3d2)
         tmp = self._new(1, 3, H, W)
