@@ -199,7 +199,7 @@ class Engine:
             self._wgrad(CV(u, 0, 9), dz0, 64, 3, "enhance.in_conv.0")
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, inp, cache_fn=None, keep=True):
+    def forward(self, inp, cache_fn=None, keep=True, skip_unused=False):
         """inp: [1,3,H,W] in [0,1].  cache_fn(L2) -> (warped last_H3, warped last_s3) (model.py:164); None on a new sequence
         (zeros, model.py:155-161).  Returns the 23 outputs in the reference order (Appendix B of SURVEY.md)."""
         o, lib, s = self.ops, self.lib, self._stream()
@@ -239,8 +239,8 @@ class Engine:
         lib.call("zt_clamp_sub6_f32", H2, s2, r5, H5p, H5p[:, 3:], H * W, s)
         H3, s3 = H5p[:, :3], H5p[:, 3:]
         # L_pred1_L_pred2_diff (model.py:194) is returned by forward() but never reaches the loss (loss.py ignores it): the
-        # training plan (keep) does not compute it
-        m_l = None if keep else o.texture_mask(Lp1, Lp2)
+        # training plan (skip_unused) does not compute it
+        m_l = None if skip_unused else o.texture_mask(Lp1, Lp2)
         H3d1, H3d2 = o.pair_down(H3)
         m_h = o.texture_mask(H3d1, H3d2)
         tmp = self._new(1, 3, H, W)
