@@ -306,8 +306,8 @@ def test_trainstep_eager_equals_manual_loop(backend, synth):
 @pytest.mark.gpu
 def test_trainstep_hipgraph_replay_equals_eager(hip_ops, synth):
     """The captured hipGraph of the steady-state step replays to the same bits as eager launches: losses of every frame, final
-    weights, Adam moments, BN running statistics and the recurrent cache (6 frames: 1 new-sequence, 1 eager steady-state,
-    capture, 3 replays)."""
+    weights, Adam moments, BN running statistics and the recurrent cache (6 frames: new-sequence, eager steady-state, capture +
+    replay, replay, a second new-sequence frame, replay)."""
     ops, dev = hip_ops
     optim = importlib.import_module("zero-tig_amd.optim")
     H, W = 128, 160
@@ -317,7 +317,8 @@ def test_trainstep_hipgraph_replay_equals_eager(hip_ops, synth):
         net = _network(ops, dev, synth, 1, of_scale=1).train()
         opt = optim.ClipAdam(net)
         ts = optim.TrainStep(net, opt, use_graph=use_graph)
-        ls = [float(ts(x.pin_memory() if use_graph else x.to(dev), is_new_seq=(t == 0)).detach()) for t, x in enumerate(host)]
+        # a new sequence starts again at frame 4 (after the capture): that frame runs eagerly, the replay resumes from its cache
+        ls = [float(ts(x.pin_memory() if use_graph else x.to(dev), is_new_seq=(t in (0, 4))).detach()) for t, x in enumerate(host)]
         assert (ts.graph is not None) == use_graph
         bn = net.enhance.conv[1]
         res.append((ls, opt.fp.flat.clone(), opt.m.clone(), bn.running_mean.clone(), int(bn.num_batches_tracked), net.last_H3.clone()))
