@@ -34,6 +34,13 @@ class Engine:
         self.sv = {}
         self.wd = {}
         self._wg, self._wg_slab = {}, {}
+        # tuning hook (off): weight gradients on a second HIP stream, forked per call and joined before the batched slab
+        # reduction.  Nothing downstream of a layer's wgrad depends on it until that reduction, but the overlap does not pay:
+        # 10.47 ms/step with the side stream against 10.27 ms without (same box, gpurun_out r03a) -- the big kernels of the two
+        # streams do not co-reside (LDS / VGPR footprints) and each fork adds a dependency edge.
+        import os
+        self._wg_side = self.dev.type == "cuda" and os.environ.get("ZT_WGRAD_STREAM", "0") == "1"
+        self._wg_stream, self._wg_keep, self._wg_forked = None, [], False
         self.training = True
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -96,9 +103,22 @@ class Engine:
             if slab is not None and ent["n"]:
                 new[:ent["n"] * per].copy_(slab[:ent["n"] * per])
             slab = self._wg_slab[pre] = new
+        if self._wg_side:
+            main = torch.cuda.current_stream(self.dev)
+            if self._wg_stream is None:
+                self._wg_stream = torch.cuda.Stream(device=self.dev)
+            self._wg_stream.wait_stream(main)                   # operands (x, dz, mask) are complete on the main stream
+            self._wg_keep.append((xv.t, dz.t if isinstance(dz, CV) else dz, relu_mask))
+            with torch.cuda.stream(self._wg_stream):
+                ent["n"] += o.wgrad_partial_bf16(xv, dz, cout, k, slab, ent["n"] * per, relu_mask=relu_mask)
+            self._wg_forked = True
+            return
         ent["n"] += o.wgrad_partial_bf16(xv, dz, cout, k, slab, ent["n"] * per, relu_mask=relu_mask)
 
     def _wgrad_flush(self):
+        if self._wg_forked:
+            torch.cuda.current_stream(self.dev).wait_stream(self._wg_stream)
+            self._wg_forked, self._wg_keep = False, []
         if not self._wg:
             return
         segs = [(self._wg_slab[pre], e["n"], e["Cin"], e["Cout"], e["K"], self.g[pre + ".weight"], self.g[pre + ".bias"])
