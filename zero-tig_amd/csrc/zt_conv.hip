@@ -1759,49 +1759,85 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && CT == 4 && NT == 4) ? 2 :
     v.w = in ? (v.w & m3) : 0u;
     return v;
   };
+  // Interior tiles (halo inside the image, full channel octets: ~95 % of the tiles at 1080p) take a uniform fast path without the
+  // per-slot clamps, bounds tests and channel masks (no extra registers: the slot's pixel / channel decomposition is recomputed).
+  // (thin-input variants, CT == 1, measured 10-20 % slower with the extra path: they keep the general one)
+  constexpr bool FASTP = CT >= 3;
+  const bool x_plain = FASTP && a.Cin == CT * 16 && a.ldx >= CT * 16, z_plain = FASTP && a.Cout == NT * 16 && a.lddz >= NT * 16 && (!MASK || a.ldmask >= NT * 16);
+  auto tile_interior = [&](int oy0, int ox0) {
+    return FASTP && oy0 - padH >= 0 && oy0 - padH + IR <= a.H && ox0 - padW >= 0 && ox0 - padW + IC <= a.W && oy0 + HTH <= a.H && ox0 + HTW <= a.W;
+  };
   auto load_tile = [&](int tile) {
     const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
+    const bool fast = tile_interior(oy0, ox0);                  // uniform
+    if (fast && x_plain) {
+      const zt_bf16* xb = a.x + (unsigned)(((oy0 - padH) * a.W + ox0 - padW) * a.ldx);
 #pragma unroll
-    for (int i = 0; i < NXL; ++i) {
-      const int e = tid + i * NTHR;
-      const int c8 = e % (CT * 2), p = e / (CT * 2);
-      int gy = oy0 - padH + p / IC, gx = ox0 - padW + p % IC;
-      gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
-      gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-      const int c = c8 * 8 + 8 <= a.ldx ? c8 * 8 : 0;
-      px[i] = *reinterpret_cast<const uint4*>(a.x + (unsigned)((gy * a.W + gx) * a.ldx + c));
+      for (int i = 0; i < NXL; ++i) {
+        int e = tid + i * NTHR;
+        e = e < IR * IC * CT * 2 ? e : 0;                       // slots beyond the tile re-read slot 0 (never written)
+        const int c8 = e % (CT * 2), p = e / (CT * 2);
+        px[i] = *reinterpret_cast<const uint4*>(xb + (unsigned)(((p / IC) * a.W + p % IC) * a.ldx + c8 * 8));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NXL; ++i) {
+        const int e = tid + i * NTHR;
+        const int c8 = e % (CT * 2), p = e / (CT * 2);
+        int gy = oy0 - padH + p / IC, gx = ox0 - padW + p % IC;
+        gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+        gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+        const int c = c8 * 8 + 8 <= a.ldx ? c8 * 8 : 0;
+        px[i] = *reinterpret_cast<const uint4*>(a.x + (unsigned)((gy * a.W + gx) * a.ldx + c));
+      }
     }
+    if (fast && z_plain) {
+      const unsigned zo = (unsigned)((oy0 * a.W + ox0) * a.lddz), mo = MASK ? (unsigned)((oy0 * a.W + ox0) * a.ldmask) : 0u;
 #pragma unroll
-    for (int i = 0; i < NZL; ++i) {
-      const int e = tid + i * NTHR;
-      const int c8 = e % (NT * 2), p = e / (NT * 2);
-      int gy = oy0 + p / HTW, gx = ox0 + p % HTW;
-      gy = gy >= a.H ? a.H - 1 : gy;
-      gx = gx >= a.W ? a.W - 1 : gx;
-      const int c = c8 * 8 + 8 <= a.lddz ? c8 * 8 : 0;
-      pz[i] = *reinterpret_cast<const uint4*>(a.dz + (unsigned)((gy * a.W + gx) * a.lddz + c));
-      if constexpr (MASK) {
-        const int cm = c8 * 8 + 8 <= a.ldmask ? c8 * 8 : 0;
-        pm[i] = *reinterpret_cast<const uint4*>(a.mask + (unsigned)((gy * a.W + gx) * a.ldmask + cm));
+      for (int i = 0; i < NZL; ++i) {
+        int e = tid + i * NTHR;
+        e = e < HTH * HTW * NT * 2 ? e : 0;
+        const int c8 = e % (NT * 2), p = e / (NT * 2);
+        const int rel = (p / HTW) * a.W + p % HTW;
+        pz[i] = *reinterpret_cast<const uint4*>(a.dz + zo + (unsigned)(rel * a.lddz + c8 * 8));
+        if constexpr (MASK) pm[i] = *reinterpret_cast<const uint4*>(a.mask + mo + (unsigned)(rel * a.ldmask + c8 * 8));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NZL; ++i) {
+        const int e = tid + i * NTHR;
+        const int c8 = e % (NT * 2), p = e / (NT * 2);
+        int gy = oy0 + p / HTW, gx = ox0 + p % HTW;
+        gy = gy >= a.H ? a.H - 1 : gy;
+        gx = gx >= a.W ? a.W - 1 : gx;
+        const int c = c8 * 8 + 8 <= a.lddz ? c8 * 8 : 0;
+        pz[i] = *reinterpret_cast<const uint4*>(a.dz + (unsigned)((gy * a.W + gx) * a.lddz + c));
+        if constexpr (MASK) {
+          const int cm = c8 * 8 + 8 <= a.ldmask ? c8 * 8 : 0;
+          pm[i] = *reinterpret_cast<const uint4*>(a.mask + (unsigned)((gy * a.W + gx) * a.ldmask + cm));
+        }
       }
     }
   };
   auto write_tile = [&](int tile) {
     const int oy0 = (tile / a.tilesX) * HTH, ox0 = (tile % a.tilesX) * HTW;
+    const bool fast = tile_interior(oy0, ox0);                  // uniform
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
       const int e = tid + i * NTHR;
       const int c8 = e % (CT * 2), p = e / (CT * 2);
-      const int gy = oy0 - padH + p / IC, gx = ox0 - padW + p % IC;
-      const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      if (e < IR * IC * CT * 2) *reinterpret_cast<uint4*>(xs + p * CIP + c8 * 8) = chan_mask(px[i], a.Cin - c8 * 8, in);
+      if (fast && x_plain) {
+        if (e < IR * IC * CT * 2) *reinterpret_cast<uint4*>(xs + p * CIP + c8 * 8) = px[i];
+      } else {
+        const int gy = oy0 - padH + p / IC, gx = ox0 - padW + p % IC;
+        const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        if (e < IR * IC * CT * 2) *reinterpret_cast<uint4*>(xs + p * CIP + c8 * 8) = chan_mask(px[i], a.Cin - c8 * 8, in);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NZL; ++i) {
       const int e = tid + i * NTHR;
       const int c8 = e % (NT * 2), p = e / (NT * 2);
-      const int gy = oy0 + p / HTW, gx = ox0 + p % HTW;
-      const bool in = gy < a.H && gx < a.W;
       uint4 g = pz[i];
       if constexpr (MASK) {
         g.x = relu_keep(g.x, pm[i].x);
@@ -1809,7 +1845,13 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && CT == 4 && NT == 4) ? 2 :
         g.z = relu_keep(g.z, pm[i].z);
         g.w = relu_keep(g.w, pm[i].w);
       }
-      if (e < HTH * HTW * NT * 2) *reinterpret_cast<uint4*>(zs + p * COP + c8 * 8) = chan_mask(g, a.Cout - c8 * 8, in);
+      if (fast && z_plain) {
+        if (e < HTH * HTW * NT * 2) *reinterpret_cast<uint4*>(zs + p * COP + c8 * 8) = g;
+      } else {
+        const int gy = oy0 + p / HTW, gx = ox0 + p % HTW;
+        const bool in = gy < a.H && gx < a.W;
+        if (e < HTH * HTW * NT * 2) *reinterpret_cast<uint4*>(zs + p * COP + c8 * 8) = chan_mask(g, a.Cout - c8 * 8, in);
+      }
     }
   };
 
