@@ -197,8 +197,10 @@ def main():
         sync()
         t0 = time.perf_counter()
         ev[0].record()
+        # from_host: the frames come from pinned host memory, the next frame's copy running on a copy stream under the current step
+        feed = optim.FramePrefetcher((host_frames[(it + k) % nfr] for k in range(a.steps)), dev) if from_host else None
         for k in range(a.steps):
-            loss = step(it, from_host)
+            loss = stepper(next(feed), is_new_seq=False) if from_host else step(it)
             ev[k + 1].record()
             it += 1
         sync()
@@ -302,7 +304,8 @@ def main():
                           "parallelism": "dp%d (one contiguous clip per rank, one 370 KB flat-bucket all-reduce per step)" % world,
                           "global_batch": world, "launch": "hipGraph replay" if a.graph else "eager"},
                "with_h2d": {"value": world * a.steps / dt_h, "ms_per_step": 1e3 * dt_h / a.steps, "ms_per_step_median": med_h,
-                            "note": "same K steps with the frame's 24.9 MB (1080p) pinned-host -> HBM copy inside every step (train.py:125)"},
+                            "note": "same K steps with every frame coming from pinned host memory (train.py:125; 24.9 MB at 1080p), the next frame's copy "
+                                    "issued on a copy stream while the current step runs (optim.FramePrefetcher, as train.py does)"},
                "roofline": roof, "roofline_extra": extra, "cpu_baseline": cpu, "final_loss": last_loss}
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -114,7 +114,8 @@ def main():
     model.train()
     for epoch in range(first_epoch, args.epochs):
         losses = []
-        for it, (inp, img_name, img_path, last_img_path) in enumerate(train_queue):
+        # pinned frames reach HBM on a copy stream, one frame ahead of the step that consumes them
+        for it, (inp, img_name, img_path, last_img_path) in enumerate(optim.FramePrefetcher(train_queue, dev)):
             if it >= steps_per_epoch:
                 break
             new_seq = it == 0 or utils.sequential_judgment(img_path[0], last_img_path[0])
