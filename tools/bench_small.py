@@ -47,7 +47,7 @@ layers = {"gru 1x5 384->256 sigmoid": Layer(384, 256, 1, 5, "sigmoid"), "3x3 256
 g = torch.cuda.CUDAGraph()
 for name, L in layers.items():
     row = []
-    for v, tag in ((2, "full"), (66, "no-epilogue"), (68, "no-K-loop"), (72, "empty"), (80, "K x4")):
+    for v, tag in ((2, "full"), (66, "no-epilogue"), (68, "no-K-loop"), (70, "prologue-only"), (72, "empty"), (80, "K x4")):
         # replay 50 launches from a hipGraph: no host launch cost in the number
         L.launch(v)
         torch.cuda.synchronize()

@@ -755,6 +755,42 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
       return;
     }
   }
+  // bf16 nhwc output without a fused operand (most RAFT layers): same transposition, bf16 -- one 16-byte store per lane instead of
+  // eight 2-byte stores that each touch four 32-byte pieces of different lines (the epilogue was ~3 us of every small-map launch:
+  // tools/bench_small.py "full" vs "no-epilogue")
+  constexpr int SPH = NT * 16 + 8;                              // staging row pitch in bf16 elements (16-byte multiple)
+  if constexpr (4 * 16 * MT * SPH * 2 <= (XS_ELEMS + WS_ELEMS) * 2) {
+    if (a.out_mode == 0 && a.epi == 0 && a.ldy % 8 == 0 && (((uintptr_t)a.y) & 15) == 0 && !(a.dbg & 2)) {      // uniform
+      __syncthreads();
+      zt_bf16* stg = smem + wave * (16 * MT * SPH);
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            stg[(m * 16 + l4 * 4 + j) * SPH + q * 16 + l15] = zt_f2bf(apply_act_fast(a.alpha * (acc[m][q][j] + bias_q[q]), a.act));
+      __builtin_amdgcn_wave_barrier();
+      if (oy < a.Ho) {
+        constexpr int C8 = NT * 2;                              // 16-byte chunks per pixel
+        for (int e = lane; e < 16 * MT * C8; e += 64) {
+          const int p = e / C8, c8 = e - p * C8;
+          const int ox = ox0 + p, co = co0 + c8 * 8;
+          if (ox < a.Wo && co < a.Cout) {
+            const uint4 v = *reinterpret_cast<const uint4*>(stg + p * SPH + c8 * 8);
+            zt_bf16* dst = (zt_bf16*)a.y + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.ldy + co;
+            if (co + 8 <= a.Cout) *reinterpret_cast<uint4*>(dst) = v;
+            else {
+              zt_bf16 t[8];
+              __builtin_memcpy(t, &v, 16);
+              for (int k = 0; k < 8 && co + k < a.Cout; ++k) dst[k] = t[k];
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
   if (oy >= a.Ho) return;
   if (a.dbg & 2) {                                              // ablation: no epilogue (accumulators kept live)
     if (acc[0][0][0] == 12345.678f) ((float*)a.y)[0] = acc[MT - 1][NT - 1][3];
