@@ -725,7 +725,7 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
   constexpr int SP = NT * 16 + 4;                               // staging row pitch in floats
   constexpr bool CAN_STAGE = 4 * 16 * MT * SP * 4 <= (XS_ELEMS + WS_ELEMS) * 2;
   if constexpr (CAN_STAGE) {
-    if (a.out_mode == 2 && a.epi == 0 && a.ldy % 4 == 0 && !(a.dbg & 2)) {      // uniform
+    if (a.out_mode == 2 && a.epi == 0 && a.ldy % 4 == 0 && !(a.dbg & 34)) {      // uniform
       __syncthreads();                                          // every wave is done with the operand tiles
       float* stg = reinterpret_cast<float*>(smem) + wave * (16 * MT * SP);
 #pragma unroll
@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
   // tools/bench_small.py "full" vs "no-epilogue")
   constexpr int SPH = NT * 16 + 8;                              // staging row pitch in bf16 elements (16-byte multiple)
   if constexpr (4 * 16 * MT * SPH * 2 <= (XS_ELEMS + WS_ELEMS) * 2) {
-    if (a.out_mode == 0 && a.epi == 0 && a.ldy % 8 == 0 && (((uintptr_t)a.y) & 15) == 0 && !(a.dbg & 2)) {      // uniform
+    if (a.out_mode == 0 && a.epi == 0 && a.ldy % 8 == 0 && (((uintptr_t)a.y) & 15) == 0 && !(a.dbg & 34)) {      // uniform
       __syncthreads();
       zt_bf16* stg = smem + wave * (16 * MT * SPH);
 #pragma unroll
@@ -785,6 +785,69 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
               __builtin_memcpy(t, &v, 16);
               for (int k = 0; k < 8 && co + k < a.Cout; ++k) dst[k] = t[k];
             }
+          }
+        }
+      }
+      return;
+    }
+  }
+  // bf16 nhwc output with a fused operand (residual add, ReLU masks, the two GRU fusions): activated values staged in fp32 so the
+  // arithmetic is the scalar path's; operands and results move as 16-byte chunks of 8 channels
+  if constexpr (CAN_STAGE) {
+    const bool al = a.ldy % 8 == 0 && (((uintptr_t)a.y) & 15) == 0 && a.ldaux % 8 == 0 && (((uintptr_t)a.aux) & 15) == 0 &&
+                    (a.epi != 4 || (a.ldy2 % 8 == 0 && a.esplit % 8 == 0 && (((uintptr_t)a.y2) & 15) == 0));
+    if (a.out_mode == 0 && a.epi != 0 && al && !(a.dbg & 34)) {  // uniform
+      __syncthreads();
+      float* stg = reinterpret_cast<float*>(smem) + wave * (16 * MT * SP);
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            stg[(m * 16 + l4 * 4 + j) * SP + q * 16 + l15] = apply_act_fast(a.alpha * (acc[m][q][j] + bias_q[q]), a.act);
+      __builtin_amdgcn_wave_barrier();
+      if (oy < a.Ho) {
+        constexpr int C8 = NT * 2;
+        for (int e = lane; e < 16 * MT * C8; e += 64) {
+          const int p = e / C8, c8 = e - p * C8;
+          const int ox = ox0 + p, co = co0 + c8 * 8;
+          if (ox >= a.Wo || co >= a.Cout) continue;
+          const size_t pix = (size_t)(n * a.Ho + oy) * a.Wo + ox;
+          const float4 va = *reinterpret_cast<const float4*>(stg + p * SP + c8 * 8);
+          const float4 vb = *reinterpret_cast<const float4*>(stg + p * SP + c8 * 8 + 4);
+          const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+          const bool second = a.epi == 4 && co >= a.esplit;     // the r half of [z | r]
+          const bool whole = co + 8 <= a.Cout;
+          const zt_bf16* up = a.aux + pix * a.ldaux + (second ? co - a.esplit : co);
+          zt_bf16* dst = second ? a.y2 + pix * a.ldy2 + (co - a.esplit) : (zt_bf16*)a.y + pix * a.ldy + co;
+          const bool need_u = a.epi != 4 || second;
+          auto combine = [&](float r, float uf, float hf) {
+            if (a.epi == 4) return second ? r * uf : r;
+            if (a.epi == 5) return (1.f - uf) * hf + uf * r;
+            if (a.epi == 1) return r * (uf > 0.f ? 1.f : 0.2f);
+            if (a.epi == 2) return r * (uf > 0.f ? 1.f : 0.f);
+            return r + uf;
+          };
+          if (whole) {                                          // registers only: no indexed local arrays (they would go to scratch)
+            uint4 uq = make_uint4(0, 0, 0, 0), hq = make_uint4(0, 0, 0, 0), oq;
+            if (need_u) uq = *reinterpret_cast<const uint4*>(up);
+            if (a.epi == 5) hq = *reinterpret_cast<const uint4*>(dst);
+            const unsigned uw[4] = {uq.x, uq.y, uq.z, uq.w}, hw[4] = {hq.x, hq.y, hq.z, hq.w};
+            unsigned ow[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float lo = combine(v[2 * k], zt_u2f(uw[k] << 16), zt_u2f(hw[k] << 16));
+              const float hi = combine(v[2 * k + 1], zt_u2f(uw[k] & 0xffff0000u), zt_u2f(hw[k] & 0xffff0000u));
+              ow[k] = zt_f2bf2(lo, hi);
+            }
+            oq = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            *reinterpret_cast<uint4*>(dst) = oq;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              if (co + k < a.Cout)
+                dst[k] = zt_f2bf(combine(v[k], need_u ? zt_bf2f(up[k]) : 0.f, a.epi == 5 ? zt_bf2f(dst[k]) : 0.f));
           }
         }
       }
@@ -2141,7 +2204,8 @@ static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, 
   a.Cout = Cout; a.CoutP = CoutP; a.ldk = ldk; a.ldy = ldy; a.ldaux = ldaux;
   a.padH = padH; a.padW = padW; a.act = act; a.epi = epi; a.out_mode = out_mode; a.alpha = alpha;
   a.y2 = (zt_bf16*)y2; a.ldy2 = ldy2; a.esplit = esplit; a.stats = stats;
-  a.dbg = variant >= 64 ? (variant - 64) : (variant >= 32 ? (variant - 32) : (variant >= 16 ? (variant - 16) : 0));   // tuning ablations, see tools/bench_conv.py / bench_small.py
+  static const int scalar_epi = getenv("ZT_TILED_SCALAR_EPI") ? atoi(getenv("ZT_TILED_SCALAR_EPI")) : 0;   // A/B knob: per-element epilogue
+  a.dbg = (variant >= 64 ? (variant - 64) : (variant >= 32 ? (variant - 32) : (variant >= 16 ? (variant - 16) : 0))) | (scalar_epi ? 32 : 0);   // tuning ablations, see tools/bench_conv.py / bench_small.py
   if (variant >= 64) variant = 2;
   if (variant >= 32) variant = 3;
   if (variant >= 16) variant = 1;
