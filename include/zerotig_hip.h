@@ -100,6 +100,9 @@ int zt_bn_bwd_reduce(const void* dy, int dt, int lddy, const void* z, int ldz, c
                          const float* mean, const float* rstd, int HW, int C, int nblk, float* partial, zt_stream_t stream);
 int zt_partial_reduce_f32(const float* partial, int nblk, int stride, int n, float* out, int accumulate, float* out2,
                           zt_stream_t stream);
+/* one launch for a BatchNorm layer's backward sums: sums[0:2C] = column sums of partial [nblk][2][C]; dbeta += sums[0:C],
+   dgamma += sums[C:2C] (torch BatchNorm2d backward, reference model.py:60-67 through autograd) */
+int zt_bn_bwd_sums_f32(const float* partial, int nblk, int C, float* dbeta, float* dgamma, float* sums, zt_stream_t stream);
 int zt_bn_bwd_apply(const void* dy, int dt, int lddy, const void* z, int ldz, const float* scale, const float* shift,
                         const float* mean, const float* rstd, const float* sums, void* dz, int lddz, int HW, int C,
                         int eval_mode, zt_stream_t stream);

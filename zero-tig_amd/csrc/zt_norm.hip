@@ -209,6 +209,29 @@ __global__ void __launch_bounds__(256) partial_reduce_kernel(const float* __rest
   }
 }
 
+// BatchNorm backward: the three column sums one layer needs from its [nblk][2][C] partials in one launch --
+// sums[0:2C] = (sum dyh, sum dyh*zhat), dbeta += sums[0:C], dgamma += sums[C:2C].  Same summation as partial_reduce_kernel.
+__global__ void __launch_bounds__(256) bn_bwd_sums_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                          float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                          float* __restrict__ sums) {
+  __shared__ double sh[256];
+  const int j = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += (double)partial[(size_t)b * 2 * C + j];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float v = (float)sh[0];
+    sums[j] = v;
+    if (j < C) dbeta[j] += v;
+    else dgamma[j - C] += v;
+  }
+}
+
 // dz = gamma*rstd * (dyh - sum_dyh/n - zhat * sum_dyh_zhat/n)
 template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z,
@@ -468,6 +491,14 @@ extern "C" int zt_partial_reduce_f32(const float* partial, int nblk, int stride,
                                      float* out2, hipStream_t stream) {
   ZT_REQUIRE(partial && n > 0 && (out || out2));
   hipLaunchKernelGGL(partial_reduce_kernel, dim3(n), dim3(256), 0, stream, partial, nblk, stride, n, out, accumulate, out2);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_bn_bwd_sums_f32(const float* partial, int nblk, int C, float* dbeta, float* dgamma, float* sums,
+                                  hipStream_t stream) {
+  ZT_REQUIRE(partial && nblk > 0 && C > 0 && dbeta && dgamma && sums);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(2 * C), dim3(256), 0, stream, partial, nblk, C, dbeta, dgamma, sums);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

@@ -306,9 +306,7 @@ class Ops:
         assert dy.t.dtype == z.t.dtype
         self.lib.call("zt_bn_bwd_reduce", dy.ptr, _dt(z.t), dy.ld, z.ptr, z.ld, scale, shift, mean, rstd, HW, C, nblk, part, self._s(z.t))
         sums = torch.empty((2, C), dtype=torch.float32, device=z.t.device)
-        self.partial_reduce(part, nblk, 2 * C, 2 * C, out=None, out2=sums)
-        self.partial_reduce(part, nblk, 2 * C, C, out=dbeta, accumulate=True)
-        self.lib.call("zt_partial_reduce_f32", part.data_ptr() + 4 * C, nblk, 2 * C, C, dgamma, 1, None, self._s(z.t))
+        self.lib.call("zt_bn_bwd_sums_f32", part, nblk, C, dbeta, dgamma, sums, self._s(z.t))
         if out is None:
             out = torch.empty((1, z.H, z.W, C), dtype=z.t.dtype, device=z.t.device)
         o = _cv(out)
