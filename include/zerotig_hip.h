@@ -90,6 +90,11 @@ int zt_norm_finalize_f32(const float* partial, int nblk, int N, int C, long long
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                          long long* num_batches_tracked, float momentum, float* scale, float* shift, float* mean_out,
                          float* rstd_out, zt_stream_t stream);
+/* InstanceNorm statistics and scale/shift in one launch (RAFT feature encoder, reference model/RAFT/extractor.py:117-191,
+   nn.InstanceNorm2d: biased variance, no affine): partial rows as zt_chan_stats_nhwc; the last workgroup of each sample writes
+   scale[n*C+c] = rstd, shift = -mean*rstd.  tickets: N zero-initialised counters, left at zero. */
+int zt_instance_norm_stats(const void* x, int dt, int ldx, int N, int HW, int C, int nblk, float* partial, float eps,
+                           unsigned* tickets, float* scale, float* shift, zt_stream_t stream);
 /* y = [outer_relu]([res +] [inner_relu](x*scale + shift)) */
 int zt_norm_apply_nhwc(const void* x, int dt, int ldx, const float* scale, const float* shift, const void* res, int ldres,
                            void* y, int ldy, int N, int HW, int C, int inner_relu, int outer_relu, zt_stream_t stream);

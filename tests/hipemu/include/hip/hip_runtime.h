@@ -148,6 +148,7 @@ template <class T> inline T shfl_from(T v, int src_lane) {
 #define warpSize 64
 
 static inline void __syncthreads() { emu::syncthreads(); }
+static inline void __threadfence() {}                               // one workgroup runs at a time: stores are already visible
 template <class T> static inline T __shfl_xor(T v, int m, int = 64) { return emu::shfl_from(v, emu::my_lane() ^ m); }
 template <class T> static inline T __shfl_down(T v, int d, int = 64) { int l = emu::my_lane(); return emu::shfl_from(v, l + d < 64 ? l + d : l); }
 template <class T> static inline T __shfl(T v, int src, int = 64) { return emu::shfl_from(v, src); }

@@ -237,6 +237,33 @@ def test_norms(backend):
     assert maxerr(dg, gam_t.grad) < 2e-4 and maxerr(db, bet_t.grad) < 2e-4
 
 
+@pytest.mark.parametrize("case", [(2, 96, 9, 14, "f32"), (2, 64, 70, 66, "bf16"), (2, 96, 23, 40, "bf16"), (1, 128, 45, 80, "f32")],
+                         ids=lambda c: "n%d_c%d_%dx%d_%s" % c)
+def test_instance_norm_one_launch(backend, case):
+    """InstanceNorm scale / shift from the statistics kernel's last workgroup (RAFT feature encoder, extractor.py:117-191) ==
+    the two-launch chan_stats + norm_finalize path, on every statistics kernel (fp32, bf16 16-byte fast path, bf16 generic);
+    called repeatedly so the ticket counters are seen to return to zero."""
+    import torch.nn.functional as F
+    ops, dev, _ = backend
+    N, C, H, W, kind = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, C, H, W, generator=g) * 1.5 + 0.4
+    if kind == "bf16":
+        x = x.bfloat16().float()
+    xd = _nhwc(x).to(dev)
+    if kind == "bf16":
+        xd = xd.bfloat16()
+    part = ops.chan_stats(xd)
+    sc0, sh0, _, _ = ops.norm_finalize(part, N, C, H * W, 0)
+    for _ in range(3):
+        sc, sh = ops.instance_norm_stats(xd)
+        assert maxerr(sc, sc0) <= 1e-6 * float(sc0.abs().max()) and maxerr(sh, sh0) <= 1e-6 * max(1.0, float(sh0.abs().max()))
+    y = ops.norm_apply(xd, sc, sh, inner_relu=True)
+    tol = 2e-5 if kind == "f32" else 2e-2
+    assert maxerr(y.float().cpu().permute(0, 3, 1, 2), F.relu(F.instance_norm(x))) < tol
+    assert int(ops._tickets[xd.device][0].abs().sum()) == 0
+
+
 def test_norms_bf16_fast_path(backend):
     """Enhancer block in bf16 storage at a size that takes the 16-byte-per-lane kernels (HW >= 4096, C % 8 == 0): train BN +
     ReLU + residual forward and backward against torch on the same bf16-rounded inputs; ragged pixel count (not a multiple of 4)."""

@@ -7,10 +7,75 @@
 
 namespace {
 
+// InstanceNorm in one launch: tickets != nullptr makes the last workgroup of sample n to finish fold the partial rows into
+// scale = rstd, shift = -mean * rstd (what norm_finalize_kernel computes in mode 0), saving the finalize launch on RAFT's feature
+// encoder (15 norm layers per call).  tickets[n] counts finished workgroups and is left at zero again.
+struct NormTail {
+  unsigned* tickets;
+  float* scale;
+  float* shift;
+  double count;
+  float eps;
+};
+
+__device__ __forceinline__ void instnorm_tail(const NormTail& t, const float* partial, int nblk, int C, int n) {
+  __shared__ unsigned last_s;
+  __shared__ double tail_s[256];
+  __shared__ double tail_q[256];
+  __threadfence();                                              // this workgroup's partial row is visible device-wide ...
+  __syncthreads();
+  if (threadIdx.x == 0) last_s = atomicAdd(t.tickets + n, 1u) == (unsigned)(nblk - 1);      // ... before its ticket is
+  __syncthreads();
+  if (!last_s) return;
+  __threadfence();                                              // acquire: the other workgroups' rows
+  const int Cb = C < 256 ? C : 256, G = 256 / Cb;
+  const int cl = threadIdx.x % Cb, grp = threadIdx.x / Cb;
+  for (int cbase = 0; cbase < C; cbase += Cb) {
+    const int c = cbase + cl;
+    double s = 0.0, q = 0.0;
+    if (grp < G && c < C) {
+      const float* pc = partial + (size_t)n * nblk * 2 * C + c;
+      for (int b = grp; b < nblk; b += 8 * G) {                 // eight rows in flight, clamped loads masked afterwards
+        float ps[8], pq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int bb = b + j * G;
+          const unsigned off = (unsigned)(bb < nblk ? bb : b) * 2u * (unsigned)C;
+          ps[j] = pc[off];
+          pq[j] = pc[off + C];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool ok = b + j * G < nblk;
+          s += ok ? (double)ps[j] : 0.0;
+          q += ok ? (double)pq[j] : 0.0;
+        }
+      }
+    }
+    tail_s[threadIdx.x] = s;
+    tail_q[threadIdx.x] = q;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+      for (int k = 1; k < G; ++k) {
+        s += tail_s[k * Cb + cl];
+        q += tail_q[k * Cb + cl];
+      }
+      const double m = s / t.count;
+      double var = q / t.count - m * m;
+      if (var < 0.0) var = 0.0;
+      const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)t.eps));
+      t.scale[n * C + c] = rstd;
+      t.shift[n * C + c] = 0.f - mean * rstd;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) t.tickets[n] = 0u;
+}
+
 // partial[((n*nblk + blk)*2 + {0:sum,1:sumsq})*C + c]
 template <typename T>
 __global__ void __launch_bounds__(256) chan_stats_kernel(const T* __restrict__ x, int ldx, int HW, int C, int nblk,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, NormTail tail) {
   __shared__ float4 sh_s[256];
   __shared__ float4 sh_q[256];
   const int Q = C >> 2, R = 256 / Q;
@@ -41,6 +106,7 @@ __global__ void __launch_bounds__(256) chan_stats_kernel(const T* __restrict__ x
     *reinterpret_cast<float4*>(o) = s;
     *reinterpret_cast<float4*>(o + C) = ss;
   }
+  if (tail.tickets) instnorm_tail(tail, partial, nblk, C, n);
 }
 
 // mode 0: instance norm (per n,c; no affine)   mode 1: train BN (N must be 1; updates running stats)   mode 2: eval BN
@@ -355,7 +421,7 @@ __global__ void __launch_bounds__(256) stats_bf16x8_kernel(const zt_bf16* __rest
                                                            int lddy, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, int HW, int C, int nblk,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, NormTail tail) {
   __shared__ float sh[2][8][256];
   const int Q8 = C >> 3, R = 256 / Q8;
   const int tid = threadIdx.x;
@@ -422,20 +488,39 @@ __global__ void __launch_bounds__(256) stats_bf16x8_kernel(const zt_bf16* __rest
       ob[C + c] = b;
     }
   }
+  if (MODE == 0 && tail.tickets) instnorm_tail(tail, partial, nblk, C, n);
 }
 
 static inline bool zt_x8_ok(const void* p, int ld, int C) { return C % 8 == 0 && ld % 8 == 0 && ((uintptr_t)p & 15) == 0 && 256 % (C / 8) == 0; }
 
+static int launch_chan_stats(const void* x, int dt, int ldx, int N, int HW, int C, int nblk, float* partial, const NormTail& tail,
+                             hipStream_t stream) {
+  if (dt == 0)
+    hipLaunchKernelGGL(chan_stats_kernel<float>, dim3(nblk, N), dim3(256), 0, stream, (const float*)x, ldx, HW, C, nblk, partial, tail);
+  else if (zt_x8_ok(x, ldx, C) && HW >= 4096)
+    hipLaunchKernelGGL(stats_bf16x8_kernel<0>, dim3(nblk, N), dim3(256), 0, stream, (const zt_bf16*)x, ldx, (const zt_bf16*)nullptr, 0,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, HW, C, nblk, partial,
+                       tail);
+  else
+    hipLaunchKernelGGL(chan_stats_kernel<zt_bf16>, dim3(nblk, N), dim3(256), 0, stream, (const zt_bf16*)x, ldx, HW, C, nblk, partial,
+                       tail);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
 extern "C" int zt_chan_stats_nhwc(const void* x, int dt, int ldx, int N, int HW, int C, int nblk, float* partial,
                                   hipStream_t stream) {
   ZT_REQUIRE(x && partial && C % 4 == 0 && C >= 4 && C <= 1024 && ldx % 4 == 0 && nblk > 0 && ((uintptr_t)x & 7) == 0);
-  if (dt == 0) hipLaunchKernelGGL(chan_stats_kernel<float>, dim3(nblk, N), dim3(256), 0, stream, (const float*)x, ldx, HW, C, nblk, partial);
-  else if (zt_x8_ok(x, ldx, C) && HW >= 4096)
-    hipLaunchKernelGGL(stats_bf16x8_kernel<0>, dim3(nblk, N), dim3(256), 0, stream, (const zt_bf16*)x, ldx, (const zt_bf16*)nullptr, 0,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, HW, C, nblk, partial);
-  else hipLaunchKernelGGL(chan_stats_kernel<zt_bf16>, dim3(nblk, N), dim3(256), 0, stream, (const zt_bf16*)x, ldx, HW, C, nblk, partial);
-  ZT_LAUNCH_CHECK();
-  return ZT_OK;
+  NormTail tail = {};
+  return launch_chan_stats(x, dt, ldx, N, HW, C, nblk, partial, tail, stream);
+}
+
+extern "C" int zt_instance_norm_stats(const void* x, int dt, int ldx, int N, int HW, int C, int nblk, float* partial, float eps,
+                                      unsigned* tickets, float* scale, float* shift, hipStream_t stream) {
+  ZT_REQUIRE(x && partial && C % 4 == 0 && C >= 4 && C <= 1024 && ldx % 4 == 0 && nblk > 0 && ((uintptr_t)x & 7) == 0);
+  ZT_REQUIRE(tickets && scale && shift && HW > 0);
+  NormTail tail = {tickets, scale, shift, (double)HW, eps};
+  return launch_chan_stats(x, dt, ldx, N, HW, C, nblk, partial, tail, stream);
 }
 
 extern "C" int zt_norm_finalize_f32(const float* partial, int nblk, int N, int C, long long count, float eps, int mode,
@@ -476,7 +561,7 @@ extern "C" int zt_bn_bwd_reduce(const void* dy, int dt, int lddy, const void* z,
   ZT_REQUIRE(dy && z && partial && C % 4 == 0 && C <= 1024);
   if (dt != 0 && HW >= 4096 && zt_x8_ok(dy, lddy, C) && zt_x8_ok(z, ldz, C))
     hipLaunchKernelGGL(stats_bf16x8_kernel<1>, dim3(nblk, 1), dim3(256), 0, stream, (const zt_bf16*)z, ldz, (const zt_bf16*)dy, lddy, scale,
-                       shift, mean, rstd, HW, C, nblk, partial);
+                       shift, mean, rstd, HW, C, nblk, partial, NormTail{});
   else if (dt == 0)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, stream, (const float*)dy, lddy, (const float*)z, ldz,
                        scale, shift, mean, rstd, HW, C, nblk, partial);

@@ -42,6 +42,7 @@ class Ops:
     def __init__(self, lib):
         self.lib = lib
         self._slab = {}
+        self._tickets = {}
 
     def _s(self, t):
         return current_stream(t.device)
@@ -271,6 +272,27 @@ class Ops:
         part = torch.empty((x.N, nblk, 2, x.C), dtype=torch.float32, device=x.t.device)
         self.lib.call("zt_chan_stats_nhwc", x.ptr, _dt(x.t), x.ld, x.N, HW, x.C, nblk, part, self._s(x.t))
         return part
+
+    def instance_norm_stats(self, x, eps=1e-5):
+        """InstanceNorm scale/shift [N, C] of a CV/tensor NHWC in one launch: the statistics kernel's last workgroup per sample
+        does the finalize (zt_norm.hip instnorm_tail).  Ticket counters come from a zero-initialised pool and return to zero."""
+        x = _cv(x)
+        HW = x.H * x.W
+        nblk = self._nblk(HW)
+        dev = x.t.device
+        pool = self._tickets.get(dev)
+        if pool is None:
+            pool = self._tickets[dev] = [torch.zeros(4096, dtype=torch.int32, device=dev), 0]
+        if pool[1] + x.N > 4096:
+            pool[1] = 0
+        tick = pool[0][pool[1]:pool[1] + x.N]
+        pool[1] += x.N
+        part = torch.empty((x.N, nblk, 2, x.C), dtype=torch.float32, device=dev)
+        scale = torch.empty((x.N, x.C), dtype=torch.float32, device=dev)
+        shift = torch.empty_like(scale)
+        self.lib.call("zt_instance_norm_stats", x.ptr, _dt(x.t), x.ld, x.N, HW, x.C, nblk, part, float(eps), tick, scale, shift,
+                      self._s(x.t))
+        return scale, shift
 
     def norm_finalize(self, part, N, C, count, mode, gamma=None, beta=None, rm=None, rv=None, nbt=None, momentum=0.1,
                       eps=1e-5, dev=None):

@@ -5,11 +5,15 @@ the convex 8x up-sampling of the last iteration only (the reference computes it 
 
 precision "fp32": exact-fp32 MFMA everywhere (parity mode).  "bf16": feature maps / GRU state / weights bf16 in HBM with fp32
 accumulation; the correlation volume, flow bookkeeping, up-sampling mask and everything downstream (warp) stay fp32."""
+import os
+
 import torch
 
 from .lib import current_stream
 from .ops import CV
 
+
+_ONE_LAUNCH_IN = os.environ.get("ZT_INSTNORM_ONE_LAUNCH", "0") == "1"
 
 class _Side:
     """`with plan._side():` runs the enclosed launches on a second HIP stream, forked from / joined back into the current one
@@ -124,9 +128,12 @@ class RaftPlan:
     def _norm(self, y, name, kind, inner_relu, res=None, outer_relu=False):
         o = self.ops
         if kind == "instance":
-            yv = CV(y)
-            part = o.chan_stats(y)
-            sc, sh, _, _ = o.norm_finalize(part, yv.N, yv.C, yv.H * yv.W, 0)
+            if _ONE_LAUNCH_IN:      # measured slower: the device-scope release in every workgroup writes back its XCD's L2
+                sc, sh = o.instance_norm_stats(y)
+            else:
+                yv = CV(y)
+                part = o.chan_stats(y)
+                sc, sh, _, _ = o.norm_finalize(part, yv.N, yv.C, yv.H * yv.W, 0)
         else:
             sc, sh = self.bn[name]
         return o.norm_apply(y, sc, sh, res=res, inner_relu=inner_relu, outer_relu=outer_relu)
