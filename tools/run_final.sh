@@ -18,7 +18,7 @@ tail -1 gpurun_out/${tag}_bench_default.err > gpurun_out/${tag}_bench1080p_bf16_
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${tag}_prof
 step 500 $R/gpurun_out/${tag}_prof.err rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_prof -o out -- python3 $R/bench.py --steps 5 --warmup 3 --cpu-baseline none
-tail -1 $R/gpurun_out/${tag}_prof.err | grep metric > $R/gpurun_out/${tag}_bench1080p_bf16_bench_line.json
+grep "\"metric\"" $R/gpurun_out/${tag}_prof.err | tail -1 > $R/gpurun_out/${tag}_bench1080p_bf16_bench_line.json
 f=$(find $R/gpurun_out/${tag}_prof -name "*kernel_stats.csv" | sort | tail -1)
 [ -n "$f" ] && cp $f $R/gpurun_out/${tag}_bench1080p_bf16_kernel_stats.csv && rm -rf $R/gpurun_out/${tag}_prof
 for ctr in FETCH_SIZE WRITE_SIZE; do
