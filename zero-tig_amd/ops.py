@@ -1,5 +1,7 @@
 """Tensor-level wrappers over the C ABI: allocate outputs with torch (plumbing), launch the HIP kernels on the
 current stream.  No compute happens in torch here."""
+import os
+
 import torch
 
 from .lib import current_stream
@@ -9,6 +11,9 @@ def _f32c(t):
     assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
     return t
 
+
+# partial rows of a statistics pass over a >= 1 Mpixel map (tuning knob)
+_NBLK_BIG = int(os.environ.get("ZT_NBLK_BIG", "1024"))
 
 class CV:
     """Channel view of an NHWC fp32 buffer [N,H,W,ld]: channels [off, off+C)."""
@@ -262,7 +267,7 @@ class Ops:
     def _nblk(self, HW):
         # one partial row per workgroup; 256 = one workgroup per CU.  More rows only lengthen the finalize kernel's serial sum
         # (10 us with 900 rows on the 180 x 320 RAFT maps, 4 us with 256) without making the statistics pass any faster.
-        return max(1, min(256 if HW < (1 << 20) else 1024, HW // 64))
+        return max(1, min(256 if HW < (1 << 20) else _NBLK_BIG, HW // 64))
 
     def chan_stats(self, x, nblk=None):
         """-> partial [N, nblk, 2, C] (sum, sum of squares) for a CV/tensor NHWC."""
