@@ -345,6 +345,12 @@ __global__ void __launch_bounds__(256) norm_apply_bf16x8_kernel(const zt_bf16* _
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const int o = (int)(i % Q8), pg = (int)(i / Q8);
   if (pg >= npg) return;
+  const int n = blockIdx.y;                                     // sample: its own scale / shift row (InstanceNorm on a batch)
+  x += (size_t)n * HW * ldx;
+  y += (size_t)n * HW * ldy;
+  if (res) res += (size_t)n * HW * ldres;
+  scale += n * C;
+  shift += n * C;
   float sc[8], sf[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
@@ -541,9 +547,11 @@ extern "C" int zt_norm_apply_nhwc(const void* x, int dt, int ldx, const float* s
                                   hipStream_t stream) {
   ZT_REQUIRE(x && y && scale && shift && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!res || ldres % 4 == 0));
   long long total4 = (long long)N * HW * (C / 4);
-  if (dt != 0 && N == 1 && HW >= 4096 && zt_x8_ok(x, ldx, C) && zt_x8_ok(y, ldy, C) && (!res || zt_x8_ok(res, ldres, C))) {
+  // elementwise: any C % 8 == 0 (the statistics kernels additionally need 256 % (C / 8) == 0), one grid row per sample
+  auto x8 = [&](const void* p, int ld) { return C % 8 == 0 && ld % 8 == 0 && ((uintptr_t)p & 15) == 0; };
+  if (dt != 0 && N <= 65535 && HW >= 4096 && x8(x, ldx) && x8(y, ldy) && (!res || x8(res, ldres))) {
     const int npg = zt_cdiv(HW, NPIX);
-    hipLaunchKernelGGL(norm_apply_bf16x8_kernel, dim3((unsigned)zt_cdivl((long long)npg * (C / 8), 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(norm_apply_bf16x8_kernel, dim3((unsigned)zt_cdivl((long long)npg * (C / 8), 256), N), dim3(256), 0, stream,
                        (const zt_bf16*)x, ldx, scale, shift, (const zt_bf16*)res, ldres, (zt_bf16*)y, ldy, HW, C, npg, inner_relu, outer_relu);
   } else if (dt == 0)
     hipLaunchKernelGGL(norm_apply_kernel<float>, dim3((unsigned)zt_cdivl(total4, 256)), dim3(256), 0, stream, (const float*)x, ldx,
