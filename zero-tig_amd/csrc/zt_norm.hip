@@ -481,17 +481,24 @@ __global__ void __launch_bounds__(256) stats_bf16x8_kernel(const zt_bf16* __rest
     sh[1][c][tid] = sb[c];
   }
   __syncthreads();
+  // rows folded as a tree (R = 256 / Q8 is a power of two): log2(R) steps of 16 LDS updates per thread; a serial fold by the
+  // Q8 threads of row 0 was 2 * 8 * R dependent LDS reads -- most of the kernel's time on the small RAFT maps
+  for (int st = R >> 1; st >= 1; st >>= 1) {
+    if (row < st) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        sh[0][c][tid] += sh[0][c][tid + st * Q8];
+        sh[1][c][tid] += sh[1][c][tid + st * Q8];
+      }
+    }
+    __syncthreads();
+  }
   if (row == 0) {
     float* ob = partial + ((size_t)(n * nblk + blk) * 2) * C + o * 8;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      float a = sa[c], b = sb[c];
-      for (int r = 1; r < R; ++r) {
-        a += sh[0][c][r * Q8 + o];
-        b += sh[1][c][r * Q8 + o];
-      }
-      ob[c] = a;
-      ob[C + c] = b;
+      ob[c] = sh[0][c][tid];
+      ob[C + c] = sh[1][c][tid];
     }
   }
   if (MODE == 0 && tail.tickets) instnorm_tail(tail, partial, nblk, C, n);
