@@ -77,6 +77,9 @@ def launch_ranks(n):
     s.close()
     procs = []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; with the legacy mode RCCL's intra-node
+        # transport setup fails in hipIpcGetMemHandle ("invalid argument").  The image exports it already; the children get it
+        # explicitly so that a caller's scrubbed environment cannot lose it.
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         out = None if r == 0 else subprocess.DEVNULL          # rank 0 prints the line on our stdout; stderr is shared
@@ -147,8 +150,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ        # under a launcher (also with ONE rank) the RCCL path runs: init + all-reduce
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     synth = importlib.import_module("zero-tig_amd.synth")
@@ -165,22 +170,28 @@ def main():
     H, W = a.height, a.width
     nfr = max(2, min(a.frames, a.steps + a.warmup + 1))
     # each rank owns its own clip (seed 2 + 1000*rank): frame-level data parallelism with per-rank recurrent cache
+    # host side of `with_h2d`: what the loader hands over in device-ingest mode -- the DECODED frame, uint8 [1,H,W,3] (the synthetic
+    # frames are quantised to k/255 like an 8-bit PNG, so the device's ToTensor reproduces the float frame bit for bit: checked)
+    net._plan()
     host_frames, frames = [], []
     for t in range(nfr):
-        hf = torch.from_numpy(synth.lowlight_frame(t, H, W, seed=2 + 1000 * rank)).pin_memory()
-        host_frames.append(hf)
-        frames.append(hf.to(dev))
+        f32 = torch.from_numpy(synth.lowlight_frame(t, H, W, seed=2 + 1000 * rank))
+        u8 = torch.round(f32[0].permute(1, 2, 0) * 255.0).to(torch.uint8).contiguous()[None].pin_memory()
+        host_frames.append(u8)
+        frames.append(f32.to(dev))
+        if t == 0:
+            assert torch.equal(net._ops.ingest_u8(u8.to(dev), size=(W, H)), frames[0]), "device ToTensor must reproduce the float frame"
         if rank == 0:
             log("synthetic frame %d/%d resident in HBM" % (t + 1, nfr))
 
-    stepper = optim.TrainStep(net, opt, use_graph=bool(a.graph))
+    stepper = optim.TrainStep(net, opt, use_graph=bool(a.graph), ingest_size=(W, H))
 
     def step(i, from_host=False):
         src = host_frames if from_host else frames
         return stepper(src[i % nfr], is_new_seq=(i == 0))
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -302,13 +313,17 @@ def main():
                "config": {"workload": "%dx%d BVI-RLV-style self-supervised training step (enhance+RAFT flow+warp+loss+backward+clip+Adam), "
                                       "batch 1 frame per GPU, of_scale=%d, dataset=%s" % (H, W, a.of_scale, a.dataset),
                           "parallelism": "dp%d (one contiguous clip per rank, one 370 KB flat-bucket all-reduce per step)" % world,
-                          "global_batch": world, "launch": "hipGraph replay" if a.graph else "eager"},
+                          "global_batch": world, "launch": "hipGraph replay" if a.graph else "eager",
+                          "collective": ("flat 370 KB gradient bucket all-reduced through torch.distributed backend '%s' (RCCL) every step, world=%d"
+                                         % (dist.get_backend(), world)) if use_dist else "none (single process, no launcher)"},
                "with_h2d": {"value": world * a.steps / dt_h, "ms_per_step": 1e3 * dt_h / a.steps, "ms_per_step_median": med_h,
-                            "note": "same K steps with every frame coming from pinned host memory (train.py:125; 24.9 MB at 1080p), the next frame's copy "
-                                    "issued on a copy stream while the current step runs (optim.FramePrefetcher, as train.py does)"},
+                            "note": "same K steps with every frame coming from pinned host memory as the loaders deliver it in device-ingest mode "
+                                    "(decoded uint8 HWC, 6.2 MB at 1080p; the reference moves 24.9 MB of fp32, train.py:125): the next frame's copy is "
+                                    "issued on a copy stream while the current step runs (optim.FramePrefetcher, as train.py does) and ToTensor "
+                                    "(+ the PIL-exact resize when the file is not 1920x1080) runs on the device (zt_ingest.hip)"},
                "roofline": roof, "roofline_extra": extra, "cpu_baseline": cpu, "final_loss": last_loss}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

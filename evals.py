@@ -36,8 +36,9 @@ def main():
     logging.basicConfig(stream=sys.stdout, level=logging.INFO, format="%(asctime)s %(message)s", datefmt="%m/%d %I:%M:%S %p")
     logging.getLogger().addHandler(logging.FileHandler(os.path.join(args.save, "log.txt")))
     dev = torch.device("cuda", args.gpu)
+    args.device_ingest = True                      # loaders decode only; resize + ToTensor (multi_read_data.py:127-132) on the GPU
     test_set = CreateDataset(args, task="test")
-    queue = torch.utils.data.DataLoader(test_set, batch_size=1, pin_memory=True, num_workers=0, shuffle=False)
+    queue = torch.utils.data.DataLoader(test_set, batch_size=1, **utils.loader_kwargs(utils.loader_workers(-1)))
     logging.info("Total image number: %d; model path = %s", len(test_set), args.model_pretrain)
     model = Finetunemodel(args).to(dev)
     model.eval()
@@ -45,12 +46,10 @@ def main():
     with torch.no_grad():
         for i, (inp, img_name, img_path, last_img_path) in enumerate(queue):
             model.is_new_seq = i == 0 or utils.sequential_judgment(img_path[0], last_img_path[0])
-            enhance, output, illum = model(inp.to(dev))            # Finetunemodel.forward updates the recurrent cache itself
+            enhance, output, illum = model(utils.ingest_frame(inp, dev))   # Finetunemodel.forward updates the recurrent cache itself
             gt_path = img_path[0].replace("input", "gt").replace("low_light_", "normal_light_")
-            gt = Image.open(gt_path).convert("RGB")
-            if gt.size != (output.shape[-1], output.shape[-2]):    # the loader resizes inputs to 1920 x 1080 (multi_read_data.py:127-132)
-                gt = gt.resize((output.shape[-1], output.shape[-2]))
-            gt_t = torch.from_numpy(np.asarray(gt, dtype=np.uint8).copy()).permute(2, 0, 1)[None].float().div_(255.0).to(dev)
+            gt = torch.from_numpy(np.asarray(Image.open(gt_path).convert("RGB"), dtype=np.uint8).copy())
+            gt_t = utils.ingest_frame(gt, dev)                     # same resize to 1920 x 1080 + ToTensor as the inputs, on the device
             psnr = utils.psnr(output, gt_t)                        # evals.py:83-85, exact integer sum on the device
             total, n = total + psnr, n + 1
             logging.info("NUM: %d, PSNR: %.3f, Total PSNR: %.3f", n, psnr, total / n)

@@ -218,6 +218,19 @@ int zt_sqdiff_u8_f32(const float* a, const float* b, long long n, unsigned long 
                      zt_stream_t stream);
 
 
+/* ---- input side (zt_ingest.hip): dataloader/multi_read_data.py:127-132 on the device -------------------------------------
+ * The loader workers decode to interleaved uint8 RGB [H][W][3]; `im.resize((1920, 1080))` (PIL default filter for RGB = BICUBIC,
+ * Pillow's 8-bit two-pass resampler) and `transforms.ToTensor()` run here, bit-identical to the host libraries.
+ * zt_resample_u8_hwc: ONE pass of the resampler along `axis` (1 = horizontal: [Hi][Wi][3] -> [Hi][Wo][3], Ho == Hi;
+ *   0 = vertical: [Hi][Wi][3] -> [Ho][Wi][3], Wo == Wi, 3*Wi % 4 == 0): out = clip8((2^21 + sum_k src[min + k] * coef[o][k]) >> 22);
+ *   coef: int32 [out][ksize] = round(w * 2^22), bounds: int32 [out][2] = (first source index, tap count) -- device arrays, computed
+ *   by the host exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc do.  Horizontal first, then vertical (Resample.c).
+ * zt_u8hwc_to_planar_f32: uint8 [H][W][3] -> planar fp32 [3][H][W], value lut256[byte] (lut256[k] = float(k) / 255.f: ToTensor). */
+int zt_resample_u8_hwc(const unsigned char* src, unsigned char* dst, int Hi, int Wi, int Ho, int Wo, int axis, const int* coef,
+                       const int* bounds, int ksize, zt_stream_t stream);
+int zt_u8hwc_to_planar_f32(const unsigned char* src, float* dst, int H, int W, const float* lut256, zt_stream_t stream);
+
+
 /* ---- hardware self-test probes (zt_probe.hip): pin the test emulator's model of gfx950 instructions to the chip ----- */
 /* ds_read_b64_tr_b16 on a [16][64] image of 16-bit codes: out[lane*4+q]; bf16 MFMA 16x16x32: D[16][16] = A[16][32] B[32][16] */
 int zt_probe_tr16(const unsigned short* img, unsigned short* out, int col0, zt_stream_t stream);

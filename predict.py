@@ -23,7 +23,7 @@ parser.add_argument("--gpu", type=int, default=0)
 parser.add_argument("--seed", type=int, default=2)
 parser.add_argument("--of_scale", type=int, default=3)
 parser.add_argument("--dataset", type=str, default="RLV")
-parser.add_argument("--num_workers", type=int, default=0)
+parser.add_argument("--num_workers", type=int, default=-1, help="decode workers; -1: host cores - 2, at most 12")
 
 
 def save_images(tensor):
@@ -37,8 +37,9 @@ def main():
     os.makedirs(args.save, exist_ok=True)
     logging.basicConfig(stream=sys.stdout, level=logging.INFO, format="%(asctime)s %(message)s")
     dev = torch.device("cuda", args.gpu)
+    args.device_ingest = True                      # loaders decode only; resize + ToTensor (multi_read_data.py:127-132) on the GPU
     test_set = CreateDataset(args, task="test")
-    queue = torch.utils.data.DataLoader(test_set, batch_size=1, pin_memory=True, num_workers=args.num_workers, shuffle=False)
+    queue = torch.utils.data.DataLoader(test_set, batch_size=1, **utils.loader_kwargs(utils.loader_workers(args.num_workers)))
     print("Total image number: ", len(test_set))
     model = Finetunemodel(args).to(dev)
     model.eval()
@@ -47,7 +48,7 @@ def main():
     with torch.no_grad():
         for i, (inp, img_name, img_path, last_img_path) in enumerate(queue):
             model.is_new_seq = i == 0 or sequential_judgment(img_path[0], last_img_path[0])
-            enhance, output, illum = model(inp.to(dev))
+            enhance, output, illum = model(utils.ingest_frame(inp, dev))
             if "RLV" == args.dataset:
                 parts = img_path[0].split(os.sep)
                 save_dir = os.path.join(args.save, parts[-3], parts[-2])

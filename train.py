@@ -34,7 +34,8 @@ parser.add_argument("--model_pretrain", type=str, help="checkpoint to start from
 parser.add_argument("--lowlight_images_path", type=str, default="", help="input data folder")
 parser.add_argument("--of_scale", type=int, default=3, help="downscale factor for optical flow")
 parser.add_argument("--dataset", type=str, default="RLV", help="dataset name")
-parser.add_argument("--num_workers", type=int, default=0, help="dataloader workers")
+parser.add_argument("--num_workers", type=int, default=-1, help="dataloader (decode) workers; -1: host cores - 2, at most 12")
+parser.add_argument("--host_ingest", action="store_true", help="resize + ToTensor on the host like the reference (default: decode only, the rest on the device)")
 parser.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"], help="bf16 throughput mode / fp32 parity mode")
 parser.add_argument("--graph", type=int, default=1, help="1: replay the steady-state step from a captured hipGraph (zero-tig_amd/optim.py:TrainStep); 0: eager launches")
 parser.add_argument("--resume", type=str, default=None, help="resume file written every epoch (model + Adam moments + step + loop position)")
@@ -95,6 +96,8 @@ def main():
     optimizer = optim.ClipAdam(model, lr=args.lr, betas=(0.9, 0.999), weight_decay=3e-4, max_norm=5.0)
     logging.info("model size = %f", utils.count_parameters_in_MB(model))
 
+    args.device_ingest = not args.host_ingest      # loaders deliver the decoded uint8 frame; resize + ToTensor run on the GPU
+    workers = utils.loader_workers(args.num_workers)
     train_set = CreateDataset(args, task="train")
     test_set = CreateDataset(args, task="test")
     # data parallelism at clip granularity: each rank walks a contiguous share of the (temporally ordered) frame list
@@ -102,9 +105,8 @@ def main():
     per = (n + world - 1) // world
     idx = list(range(rank * per, min(n, (rank + 1) * per)))
     steps_per_epoch = per if world == 1 else min(len(range(r * per, min(n, (r + 1) * per))) for r in range(world))
-    train_queue = torch.utils.data.DataLoader(torch.utils.data.Subset(train_set, idx), batch_size=1, pin_memory=True,
-                                              num_workers=args.num_workers, shuffle=False)
-    test_queue = torch.utils.data.DataLoader(test_set, batch_size=1, pin_memory=True, num_workers=args.num_workers, shuffle=False)
+    train_queue = torch.utils.data.DataLoader(torch.utils.data.Subset(train_set, idx), batch_size=1, **utils.loader_kwargs(workers))
+    test_queue = torch.utils.data.DataLoader(test_set, batch_size=1, **utils.loader_kwargs(min(workers, 4)))
 
     stepper = optim.TrainStep(model, optimizer, use_graph=bool(args.graph))
     total_step, first_epoch = 0, 0
@@ -114,6 +116,7 @@ def main():
     model.train()
     for epoch in range(first_epoch, args.epochs):
         losses = []
+        t_epoch = time.perf_counter()
         # pinned frames reach HBM on a copy stream, one frame ahead of the step that consumes them
         for it, (inp, img_name, img_path, last_img_path) in enumerate(optim.FramePrefetcher(train_queue, dev)):
             if it >= steps_per_epoch:
@@ -125,6 +128,11 @@ def main():
             losses.append(loss.item())
             logging.info("train-epoch %03d %03d %f", epoch, it, losses[-1])
         logging.info("train-epoch %03d %f", epoch, np.average(losses))
+        torch.cuda.synchronize(dev)
+        dt_epoch = time.perf_counter() - t_epoch
+        logging.info("train-epoch %03d throughput: %d frames in %.2f s = %.1f frames/s per rank, files -> decode (%d workers) -> %s -> step",
+                     epoch, len(losses), dt_epoch, len(losses) / max(dt_epoch, 1e-9), workers,
+                     "PCIe (uint8) -> device resize + ToTensor" if args.device_ingest else "host resize + ToTensor -> PCIe (fp32)")
         if rank == 0:
             utils.save(model, os.path.join(model_path, "weights_%d.pt" % epoch))        # the reference's plain state_dict (train.py:135)
         utils.save_checkpoint(model, optimizer, os.path.join(model_path, "resume.pt"), epoch=epoch + 1, step=total_step)
@@ -134,7 +142,7 @@ def main():
             with torch.no_grad():
                 for it, (inp, img_name, img_path, last_img_path) in enumerate(test_queue):
                     model.is_new_seq = it == 0 or utils.sequential_judgment(img_path[0], last_img_path[0])
-                    outs = model(inp.to(dev))
+                    outs = model(utils.ingest_frame(inp, dev))
                     H2, H3 = outs[6], outs[13]
                     name = "%s_%s" % (os.path.basename(os.path.split(img_path[0])[0]), img_name[0])
                     os.makedirs(args.save + "/result/denoise/", exist_ok=True)

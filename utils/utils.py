@@ -77,6 +77,39 @@ class InputPadder:                                           # utils.py:233-251 
         return x[..., c[0]:c[1], c[2]:c[3]]
 
 
+def ingest_frame(frame, device):
+    """Loader item -> fp32 [1,3,H,W] on `device`: a float frame is copied; a decoded uint8 [1,H0,W0,3] frame (the loaders'
+    device-ingest mode) goes through `im.resize((1920, 1080))` + `ToTensor()` of multi_read_data.py:127-132 on the device."""
+    if frame.dtype == torch.uint8:
+        return _ops().ingest_u8(frame.to(device, non_blocking=True))
+    return frame.to(device, non_blocking=True)
+
+
+def loader_workers(requested):
+    """DataLoader worker count: `requested` >= 0 as given; -1 (default of this repo's scripts) = the host cores this process may
+    use minus two, at most 12 -- PNG decode of a 1080p frame costs ~30-40 ms of one core, the GPU step 10 ms."""
+    if requested is not None and requested >= 0:
+        return requested
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(0, min(12, n - 2))
+
+
+def loader_kwargs(workers):
+    """DataLoader arguments of this repo's scripts.  Workers are SPAWNED, not forked: the parent has initialised the GPU by the
+    time the loader starts, and a decode worker must not inherit any of that state (it only runs PIL)."""
+    extra = dict(persistent_workers=True, prefetch_factor=4, multiprocessing_context="spawn") if workers > 0 else {}
+    return dict(num_workers=workers, pin_memory=True, shuffle=False, **extra)
+
+
 def quantize_u8(tensor, round_half_even=False):
     """[1,3,H,W] in [0,1] on the device -> uint8 [H,W,3] on the device: predict.py:57-61 `save_images` (truncation) or, with
     round_half_even, evals.py:83-84 `np.round(x * 255).astype(np.uint8)`."""

@@ -165,6 +165,27 @@ __device__ __forceinline__ void zt_glds16(const void* gsrc, void* lds_wave_base)
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same DMA, issued from inline asm so that hipcc does not know about it.  Why: with the builtin form hipcc (ROCm 7.2) treats
+// every pending LDS-DMA as a pending LDS write that any later LDS access it cannot disambiguate may alias -- and it cannot
+// disambiguate the transposing read intrinsic (ds_read_b64_tr_b16): it puts `s_waitcnt vmcnt(0)` in front of the first such read
+// after the DMA issue, i.e. the "prefetch" of the next tile is waited for before the current tile's MFMA loop starts (seen in the
+// .s of the first build of wgrad64_dma_bf16_kernel).  Hidden from the compiler, the DMA is ours to order: ZT_WAIT_HIDDEN_DMA()
+// (s_waitcnt vmcnt(0)) by every issuing wave, then a workgroup barrier, then the reads (cdna_hip_programming.md 5.7 item 1).
+// M0 carries the wave-uniform LDS destination; it is compiler-reserved, so it is saved, set and restored inside ONE statement.
+// The host-side test emulator pre-defines both macros (immediate copy / no-op).
+#ifndef ZT_GLDS16_HIDDEN
+__device__ __forceinline__ void zt_glds16_hidden_(const void* gsrc, void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+#define ZT_GLDS16_HIDDEN(gsrc, lds_wave_base) zt_glds16_hidden_((gsrc), (lds_wave_base))
+#define ZT_WAIT_HIDDEN_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 // s_waitcnt vmcnt(0) only (gfx9 encoding: vmcnt = simm16[15:14|3:0], expcnt [6:4] and lgkmcnt [11:8] left at their maxima)
 __device__ __forceinline__ void zt_wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 // s_waitcnt vmcnt(N), N < 16: all but the N most recently issued vector-memory operations have completed (in-order counter)

@@ -2046,6 +2046,195 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && CT == 4 && NT == 4) ? 2 :
   }
 }
 
+// ---- 64 -> 64 3x3 weight gradient (Enhancer conv.0: 3 launches per step), LDS-DMA form.
+// Same MFMA decomposition as wgrad_mfma_bf16_kernel<3,3,4,4,8> (8 waves share the 36 (tap, ci-tile) pairs of an 8-row x 32-pixel
+// tile; K = pixels through ds_read_b64_tr_b16), but
+//  * both operand tiles go global -> LDS by DMA (`global_load_lds_dwordx4`): no staging registers, no ds_write pass, nothing of the
+//    staging in any wave's instruction stream except the ~10 DMA issues per wave and tile;
+//  * TWO tile buffers (2 x (10 x 34 + 8 x 32) pixels x 128 B = 149 KB): tile k+1 lands while tile k's MFMA loop runs, ONE barrier
+//    per tile;
+//  * pixel rows are exactly 128 B (a DMA destination is lane-linear, so rows cannot be padded) and XOR-swizzled at 32-byte (ci-tile)
+//    granularity by s(col) = bit1(col) | bit3(col) << 1 -- applied to the SOURCE address of the DMA and to the read address.  A
+//    transposing read's 32-lane half covers pixels {c..c+3, c+8..c+11} x 32 B: unswizzled these are 4-way bank conflicts on 128-B
+//    rows (and 41 % of the LDS cycles on the former 144-byte-pitch image); with the swizzle every read is conflict-free (brute force
+//    over all kx / ci-tile / row / half: DESIGN section 5);
+//  * the bias gradient (column sums of dz) is an MFMA with an all-ones A fragment in the pair slot that wave 4 had idle (36 pairs
+//    over 8 waves) instead of 32 two-byte LDS reads + adds per thread and tile;
+//  * XCD-aware banded tile order as in conv_rs, so a tile's halo rows / columns are in its XCD's L2.
+// Requires Cin == Cout == 64 and channel strides >= 64 (multiples of 8).
+constexpr int WG64_IR = 10, WG64_IC = 34, WG64_XE = WG64_IR * WG64_IC * 64, WG64_ZE = 8 * HTW * 64;
+
+__device__ __forceinline__ int wg64_swz(int col) { return ((col >> 1) & 1) | (((col >> 3) & 1) << 1); }
+
+__global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) {
+  constexpr int NW = 8, NTHR = 512, HTH = 8, IR = WG64_IR, IC = WG64_IC, CT = 4, NT = 4;
+  constexpr int NPAIR = 36, PPW = 5;
+  constexpr int NGX = (IR * IC * 8 + NTHR - 1) / NTHR, NGZ = HTH * HTW * 8 / NTHR;          // DMA wave-instructions per wave and tile: 6 + 4
+  __shared__ __attribute__((aligned(16))) zt_bf16 smem[2 * (WG64_XE + WG64_ZE)];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g8 = (lane >> 4) * 8;
+  const int trq = l15 >> 2, trp = (l15 & 3) * 4;
+
+  // XCD-aware tile order (see conv_rs): workgroup b runs on XCD b % 8; an XCD's run of tiles walks bands of 4 tile rows column-major
+  const int G = gridDim.x;
+  const int pb = (G % 8 == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+  const int tilesY = a.ntiles / a.tilesX;
+  auto tile_xy = [&](int idx, int& ty, int& tx) {
+    const int band = idx / (4 * a.tilesX), r = idx - band * 4 * a.tilesX;
+    const int rows = tilesY - band * 4 < 4 ? tilesY - band * 4 : 4;
+    tx = r / rows;
+    ty = band * 4 + r - tx * rows;
+  };
+
+  auto dma_tile = [&](int idx, int buf) {
+    int ty, tx;
+    tile_xy(idx, ty, tx);
+    const int oy0 = ty * HTH, ox0 = tx * HTW;
+    zt_bf16* xb = smem + buf * (WG64_XE + WG64_ZE);
+    zt_bf16* zb = xb + WG64_XE;
+    int ln = lane;
+    ZT_OPAQUE(ln);                                              // slot geometry recomputed per tile, not kept in registers
+    const bool interior = oy0 - 1 >= 0 && oy0 - 1 + IR <= a.H && ox0 - 1 >= 0 && ox0 - 1 + IC <= a.W;      // uniform
+#pragma unroll
+    for (int i = 0; i < NGX; ++i) {
+      const int e = (i * NW + wave) * 64 + ln;
+      const int p = e >> 3, row = p / IC, col = p - row * IC;
+      const int cj = (e & 7) ^ (wg64_swz(col) << 1);            // logical 16-byte chunk that lands in physical chunk e & 7
+      const int gy = oy0 - 1 + row, gx = ox0 - 1 + col;
+      const void* src;
+      if (interior) {
+        src = a.x + (unsigned)((gy * a.W + gx) * a.ldx + cj * 8);
+      } else {
+        const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const int gyc = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+        src = in ? (const void*)(a.x + (unsigned)((gyc * a.W + gxc) * a.ldx + cj * 8)) : (const void*)&zt_zero_chunk;
+      }
+      if ((i * NW + NW) * 64 <= IR * IC * 8 || e < IR * IC * 8) ZT_GLDS16_HIDDEN(src, xb + (i * NW + wave) * 512);
+    }
+    const bool zin = oy0 + HTH <= a.H && ox0 + HTW <= a.W;       // uniform
+#pragma unroll
+    for (int i = 0; i < NGZ; ++i) {
+      const int e = (i * NW + wave) * 64 + ln;
+      const int p = e >> 3, row = p / HTW, col = p - row * HTW;
+      const int cj = (e & 7) ^ (wg64_swz(col) << 1);
+      const int gy = oy0 + row, gx = ox0 + col;
+      const void* src;
+      if (zin) {
+        src = a.dz + (unsigned)((gy * a.W + gx) * a.lddz + cj * 8);
+      } else {
+        const bool in = gy < a.H && gx < a.W;
+        const int gyc = gy >= a.H ? a.H - 1 : gy, gxc = gx >= a.W ? a.W - 1 : gx;
+        src = in ? (const void*)(a.dz + (unsigned)((gyc * a.W + gxc) * a.lddz + cj * 8)) : (const void*)&zt_zero_chunk;
+      }
+      ZT_GLDS16_HIDDEN(src, zb + (i * NW + wave) * 512);
+    }
+  };
+
+  zt_f32x4 acc[PPW][NT];
+#pragma unroll
+  for (int p = 0; p < PPW; ++p)
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[p][q] = (zt_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane fragment offsets (elements) inside a tile buffer: pair slot pi -> (tap, ci-tile); pairs 36..39 do not exist: wave 4's
+  // spare slot carries the bias sums (A = ones), the spare slots of waves 5..7 recompute pair 35 into a discarded accumulator
+  int alo[PPW], ahi[PPW];
+#pragma unroll
+  for (int pi = 0; pi < PPW; ++pi) {
+    int pr = wave + NW * pi;
+    pr = pr < NPAIR ? pr : NPAIR - 1;
+    const int tap = pr / CT, cit = pr - tap * CT;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int c0 = kx + g8 + trq, c1 = c0 + 4;
+    alo[pi] = (ky * IC + c0) * 64 + ((cit ^ wg64_swz(c0)) * 16) + trp;
+    ahi[pi] = (ky * IC + c1) * 64 + ((cit ^ wg64_swz(c1)) * 16) + trp;
+  }
+  int blo[NT], bhi[NT];
+  {
+    const int c0 = g8 + trq, c1 = c0 + 4;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      blo[q] = c0 * 64 + ((q ^ wg64_swz(c0)) * 16) + trp;
+      bhi[q] = c1 * 64 + ((q ^ wg64_swz(c1)) * 16) + trp;
+    }
+  }
+  const bool ones_slot = wave == 4;                              // uniform: pair slot PPW - 1 of wave 4 = bias column sums
+  const zt_s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};     // bf16 1.0
+
+  const int n_my = pb < a.ntiles ? (a.ntiles - 1 - pb) / G + 1 : 0;
+  if (n_my > 0) dma_tile(pb, 0);
+  for (int k = 0; k < n_my; ++k) {
+    ZT_WAIT_HIDDEN_DMA();             // this wave's pieces of tile k have landed ...
+    __syncthreads();                  // ... and so have everyone else's; every wave has left tile k-1's loop (its buffer is free)
+    if (k + 1 < n_my) dma_tile(pb + (k + 1) * G, (k + 1) & 1);
+    const zt_bf16* xs = smem + (k & 1) * (WG64_XE + WG64_ZE);
+    const zt_bf16* zs = xs + WG64_XE;
+    // one flat software pipeline over the 8 rows x 5 pair slots (see wgrad_mfma_bf16_kernel): A fragments LA steps ahead, a row's
+    // B fragments one row ahead; indices past the tile's end are clamped (re-reads, results unused)
+    constexpr int RB = 4, NS = RB * PPW, AD = 4, LA = 3;
+    zt_s16x4 fal[AD], fah[AD];
+    zt_s16x8 bv[2][NT];
+    auto load_a = [&](auto bc, int row, auto pc) {
+      constexpr int bi = decltype(bc)::value, pi = decltype(pc)::value;
+      const zt_bf16* xr = xs + (row < HTH ? row : HTH - 1) * IC * 64;
+      fal[bi] = zt_lds_read_tr16(xr + alo[pi]);
+      fah[bi] = zt_lds_read_tr16(xr + ahi[pi]);
+    };
+    auto load_b = [&](auto bc, int row) {
+      constexpr int bi = decltype(bc)::value;
+      const zt_bf16* zr = zs + (row < HTH ? row : HTH - 1) * HTW * 64;
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        const zt_s16x4 lo = zt_lds_read_tr16(zr + blo[q]);
+        const zt_s16x4 hi = zt_lds_read_tr16(zr + bhi[q]);
+        bv[bi][q] = (zt_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    };
+    load_b(ZtIdx<0>{}, 0);
+    zt_static_for<0, LA>([&](auto sc) {
+      constexpr int st = decltype(sc)::value;
+      load_a(ZtIdx<st % AD>{}, st / PPW, ZtIdx<st % PPW>{});
+    });
+#pragma unroll 1
+    for (int r0 = 0; r0 < HTH; r0 += RB) {
+      zt_static_for<0, NS>([&](auto sc) {
+        constexpr int st = decltype(sc)::value;
+        constexpr int rl = st / PPW, pi = st % PPW, cur = st % AD;
+        if constexpr (pi == 0) load_b(ZtIdx<(rl + 1) & 1>{}, r0 + rl + 1);
+        {
+          constexpr int nx = st + LA;
+          load_a(ZtIdx<nx % AD>{}, r0 + nx / PPW, ZtIdx<nx % PPW>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        zt_s16x8 av = (zt_s16x8){fal[cur][0], fal[cur][1], fal[cur][2], fal[cur][3], fah[cur][0], fah[cur][1], fah[cur][2], fah[cur][3]};
+        if constexpr (pi == PPW - 1) av = ones_slot ? ones : av;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[pi][q] = zt_mfma_bf16(av, bv[rl & 1][q], acc[pi][q]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+  }
+  // slab of this workgroup: [tap][ci 64][co 64] + [co 64] (same layout as wgrad_mfma_bf16_kernel)
+  float* out = a.slab + (size_t)blockIdx.x * (9 * 64 * 64 + 64);
+  const int l4 = lane >> 4;
+#pragma unroll
+  for (int pi = 0; pi < PPW; ++pi) {
+    const int pr = wave + NW * pi;
+    if (pr < NPAIR) {
+      const int tap = pr / CT, cit = pr - tap * CT;
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[((size_t)tap * 64 + cit * 16 + l4 * 4 + j) * 64 + q * 16 + l15] = acc[pi][q][j];
+    }
+  }
+  if (ones_slot && l4 == 0) {          // every row of the ones product holds the column sums: row 0 (lanes 0..15, register 0)
+#pragma unroll
+    for (int q = 0; q < NT; ++q) out[9 * 64 * 64 + q * 16 + l15] = acc[PPW - 1][q][0];
+  }
+}
+
 template <int KH, int KW>
 int launch_wgrad_h(const WgradArgsH& a, int CT, int NT, int nblk, hipStream_t stream) {
   dim3 grid(nblk);
@@ -2064,6 +2253,12 @@ int launch_wgrad_h(const WgradArgsH& a, int CT, int NT, int nblk, hipStream_t st
   if (CT == 4 && NT == 4) {
     static const int nw4 = getenv("ZT_WGRAD_NW4") ? atoi(getenv("ZT_WGRAD_NW4")) : 0;      // tuning hook: 4-wave / 4-row form
     if (nw4) { ZT_WG(4, 4, 4); }
+    const int dma = getenv("ZT_WGRAD_DMA") ? atoi(getenv("ZT_WGRAD_DMA")) : 1;             // 0: the register-staged form (A/B: tests, tools/bench_wgrad.py)
+    if (dma && KH == 3 && KW == 3 && a.Cin == 64 && a.Cout == 64 && a.ldx >= 64 && a.lddz >= 64 && a.ldx % 8 == 0 && a.lddz % 8 == 0 &&
+        a.ntiles % a.tilesX == 0) {
+      hipLaunchKernelGGL(wgrad64_dma_bf16_kernel, grid, dim3(512), 0, stream, a);
+      return 0;
+    }
     ZT_WG(4, 4, 8);
   }
   if (CT == 4 && NT == 1) { ZT_WG(4, 1, 4); }

@@ -293,10 +293,8 @@ class Network(_ZeroTIGBase):
             self.last_H3_wp, self.last_s3_wp = eng.last_wp
         else:
             # the cache update needs L2 of the CURRENT frame (model.py:164), which the engine produces first
-            # `_teacher_flow` (parity tests only): warp with the oracle's flow instead of the plan's own RAFT result, which isolates
-            # everything downstream of RAFT at the new-sequence tolerance (tests/test_scale_gpu.py)
-            outs = eng.forward(x, keep=keep, skip_unused=keep, cache_fn=lambda L2: rp.update_cache(
-                self.last_H3, self.last_s3, L2, self.of_scale, flow_up=self.__dict__.get("_teacher_flow")))
+            outs = eng.forward(x, keep=keep, skip_unused=keep,
+                               cache_fn=lambda L2: rp.update_cache(self.last_H3, self.last_s3, L2, self.of_scale))
             self.last_H3_wp, self.last_s3_wp = eng.last_wp
         return outs
 

@@ -179,6 +179,45 @@ class Ops:
         self.lib.call("zt_quantize_u8_hwc", x, out, H, W, int(mode), self._s(x))
         return out
 
+    def ingest_u8(self, u8, out=None, size=(1920, 1080)):
+        """Decoded frame, uint8 [H0,W0,3] (or [1,H0,W0,3]) on the device -> fp32 [1,3,H,W] in [0,1]: the reference loader's
+        `im.resize(size)` (PIL BICUBIC, 8-bit two-pass; skipped when the frame already has that size, as PIL does) followed by
+        `ToTensor()` (multi_read_data.py:127-132), bit-identical to the host libraries.  size = (W, H) like PIL; None = keep."""
+        from . import ingest
+        if u8.dim() == 4:
+            assert u8.shape[0] == 1
+            u8 = u8[0]
+        assert u8.dtype == torch.uint8 and u8.dim() == 3 and u8.shape[2] == 3 and u8.is_contiguous()
+        dev, s = u8.device, self._s(u8)
+        H0, W0 = int(u8.shape[0]), int(u8.shape[1])
+        W, H = (W0, H0) if size is None else size
+        cache = self.__dict__.setdefault("_ingest_tables", {})
+
+        def tables(n_in, n_out):
+            key = (n_in, n_out, str(dev))
+            if key not in cache:
+                coef, bounds, ks = ingest.pil_bicubic_tables(n_in, n_out)
+                cache[key] = (torch.from_numpy(coef).to(dev), torch.from_numpy(bounds).to(dev), ks)
+            return cache[key]
+        if ("lut", str(dev)) not in cache:
+            cache[("lut", str(dev))] = torch.from_numpy(ingest.to_tensor_lut()).to(dev)
+        cur = u8
+        if W0 != W:                                           # Resample.c: horizontal pass first, into an 8-bit image
+            coef, bounds, ks = tables(W0, W)
+            nxt = torch.empty((H0, W, 3), dtype=torch.uint8, device=dev)
+            self.lib.call("zt_resample_u8_hwc", cur, nxt, H0, W0, H0, W, 1, coef, bounds, ks, s)
+            cur = nxt
+        if H0 != H:
+            coef, bounds, ks = tables(H0, H)
+            nxt = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+            self.lib.call("zt_resample_u8_hwc", cur, nxt, H0, W, H, W, 0, coef, bounds, ks, s)
+            cur = nxt
+        if out is None:
+            out = torch.empty((1, 3, H, W), dtype=torch.float32, device=dev)
+        assert tuple(out.shape) == (1, 3, H, W) and out.dtype == torch.float32 and out.is_contiguous()
+        self.lib.call("zt_u8hwc_to_planar_f32", cur, out, H, W, cache[("lut", str(dev))], s)
+        return out
+
     def psnr_u8(self, a, b):
         """evals.py:83-85: cv2.PSNR of round(a*255), round(b*255) -> python float (inf when identical); one 8-byte read-back."""
         _f32c(a), _f32c(b)

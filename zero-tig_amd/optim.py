@@ -101,7 +101,7 @@ class ClipAdam:
         self._check_binding()
         fp = self.fp
         ws = self.world()
-        if ws > 1:
+        if dist.is_available() and dist.is_initialized():        # also with ONE rank: the same RCCL call the N-rank job makes
             dist.all_reduce(fp.grad, op=dist.ReduceOp.SUM, group=self.pg)
         self.t += 1
         lib = self.model._ops.lib
@@ -122,8 +122,9 @@ class TrainStep:
     frames (rare: once per clip) and the gradient all-reduce + clip + Adam launch (which takes the host-side step count) stay
     eager.  The model must not be moved, and `last_H3 / last_s3` must not be re-assigned by the caller, after the capture."""
 
-    def __init__(self, model, optimizer, use_graph=True):
-        self.model, self.opt, self.use_graph = model, optimizer, use_graph
+    def __init__(self, model, optimizer, use_graph=True, ingest_size=(1920, 1080)):
+        """ingest_size: (W, H) that decoded uint8 frames are resized to (the reference loader's fixed 1920 x 1080); None = keep."""
+        self.model, self.opt, self.use_graph, self.ingest_size = model, optimizer, use_graph, ingest_size
         self.graph, self.x, self.loss, self.n_eager_steady, self._mode = None, None, None, 0, None
 
     def _body(self, x):
@@ -133,6 +134,19 @@ class TrainStep:
         loss, _ = self.model._loss_and_grads(x, into=opt.fp.grad)
         return loss.reshape(())
 
+    def _load(self, frame, dev, out=None):
+        """frame -> fp32 [1,3,H,W] on the device.  uint8 [1,H0,W0,3] / [H0,W0,3] frames (the loaders' device-ingest mode: decoded
+        only) go through the ingest kernels: PIL-exact resize to 1920x1080 + ToTensor (multi_read_data.py:127-132), written
+        straight into `out` when given."""
+        import torch
+        if frame.dtype == torch.uint8:
+            self.model._plan()
+            return self.model._ops.ingest_u8(frame.to(dev, non_blocking=True), out=out, size=self.ingest_size)
+        if out is None:
+            return frame.to(dev, non_blocking=True)
+        out.copy_(frame, non_blocking=True)
+        return out
+
     def __call__(self, frame, is_new_seq=False):
         import torch
         m = self.model
@@ -140,19 +154,24 @@ class TrainStep:
         dev = self.opt.fp.flat.device
         if not self.use_graph:
             with torch.no_grad():
-                loss = self._body(frame.to(dev, non_blocking=True))
+                loss = self._body(self._load(frame, dev))
             self.opt.step()
             return loss
-        if self.graph is not None and (self._mode != m.training or tuple(self.x.shape) != tuple(frame.shape)):
+        if frame.dtype == torch.uint8:
+            Wi, Hi = self.ingest_size if self.ingest_size is not None else (frame.shape[-2], frame.shape[-3])
+            shape = (1, 3, Hi, Wi)
+        else:
+            shape = tuple(frame.shape)
+        if self.graph is not None and (self._mode != m.training or tuple(self.x.shape) != shape):
             # BatchNorm mode (the reference trains epochs >= 1 in eval mode, train.py:138) or the frame size changed: the captured
             # launch sequence no longer applies -> capture again after one eager step
             self.graph, self.n_eager_steady = None, 0
-            if tuple(self.x.shape) != tuple(frame.shape):
+            if tuple(self.x.shape) != shape:
                 self.x = None
         if self.x is None:
-            self.x = torch.empty(frame.shape, dtype=torch.float32, device=dev)
-            m.enable_static_cache(frame.shape)
-        self.x.copy_(frame, non_blocking=True)
+            self.x = torch.empty(shape, dtype=torch.float32, device=dev)
+            m.enable_static_cache(shape)
+        self._load(frame, dev, out=self.x)
         if is_new_seq or m.last_H3 is None or self.n_eager_steady < 1:
             # eager: new-sequence frames, and the first steady-state frame (loads every kernel's code object, sizes the slabs and
             # the plan's persistent buffers before anything is captured)
@@ -176,7 +195,8 @@ class TrainStep:
 class FramePrefetcher:
     """Host -> HBM copies of the NEXT frame on a copy stream while the current step computes (train.py:125 does a blocking
     `.cuda()` per step: 24.9 MB at 1080p, ~0.8 ms on the compute stream).  `frames` is any iterable of items whose first element
-    (or the item itself) is a pinned [1,3,H,W] fp32 tensor; iteration yields the same items with that tensor replaced by a device
+    (or the item itself) is a pinned [1,3,H,W] fp32 tensor -- or, in the loaders' device-ingest mode, the decoded uint8 [1,H0,W0,3]
+    frame (6 MB instead of 25 MB at 1080p; `TrainStep` runs the ingest kernels on it); iteration yields the same items with that tensor replaced by a device
     tensor that is ready on the current stream.  Two device buffers alternate."""
 
     def __init__(self, frames, device):
@@ -197,8 +217,8 @@ class FramePrefetcher:
             return
         host = item[0] if isinstance(item, (tuple, list)) else item
         b = self.buf[self.k]
-        if b is None or b.shape != host.shape:
-            b = self.buf[self.k] = torch.empty(host.shape, dtype=torch.float32, device=self.dev)
+        if b is None or b.shape != host.shape or b.dtype != host.dtype:
+            b = self.buf[self.k] = torch.empty(host.shape, dtype=host.dtype, device=self.dev)
         self.copy_stream.wait_stream(torch.cuda.current_stream(self.dev))       # the buffer's previous consumer has been enqueued
         with torch.cuda.stream(self.copy_stream):
             b.copy_(host, non_blocking=True)

@@ -270,12 +270,9 @@ class RaftPlan:
         self.lib.call("zt_convex_upsample_f32", st.F4, 4, mask, 576, flow_up, flow_low, h, w, current_stream(self.dev))
         return flow_low, flow_up, mask
 
-    def update_cache(self, last_H3, last_s3, L2, of_scale, want_aux=False, flow_up=None):
-        """model.py:221-259: down-scale, equalise the current frame, RAFT(12), backward-warp both cached tensors.
-        flow_up: parity tests only -- warp with this [1,2,Hp,Wp] flow (the oracle's) instead of running RAFT."""
+    def update_cache(self, last_H3, last_s3, L2, of_scale, want_aux=False):
+        """model.py:221-259: down-scale, equalise the current frame, RAFT(12), backward-warp both cached tensors."""
         o = self.ops
-        if flow_up is not None:
-            return o.warp2(flow_up.contiguous(), last_H3.contiguous(), last_s3.contiguous())
         _, _, H, W = last_H3.shape
         ht, wd = H // of_scale, W // of_scale
         a = o.resize_bilinear(last_H3.contiguous(), ht, wd, 255.0)
