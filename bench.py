@@ -205,11 +205,17 @@ def main():
     def timed(from_host):
         nonlocal it
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        # from_host: the frames come from pinned host memory, the next frame's copy running on a copy stream under the current step.
+        # Two untimed steps first: the prefetcher allocates its two device buffers and the ingest kernel's table on first use
+        # (hipMalloc synchronises), which is start-up cost of the loop, not of a step.
+        feed = optim.FramePrefetcher((host_frames[(it + k) % nfr] for k in range(a.steps + 2)), dev) if from_host else None
+        if from_host:
+            for _ in range(2):
+                stepper(next(feed), is_new_seq=False)
+                it += 1
         sync()
         t0 = time.perf_counter()
         ev[0].record()
-        # from_host: the frames come from pinned host memory, the next frame's copy running on a copy stream under the current step
-        feed = optim.FramePrefetcher((host_frames[(it + k) % nfr] for k in range(a.steps)), dev) if from_host else None
         for k in range(a.steps):
             loss = stepper(next(feed), is_new_seq=False) if from_host else step(it)
             ev[k + 1].record()
@@ -235,7 +241,7 @@ def main():
     px = float(H) * W
     h8, w8 = ((H // a.of_scale + 7) // 8), ((W // a.of_scale + 7) // 8)
     npx = h8 * w8
-    prof = {"match": {(3, 3, 1, 64, 64, H, W): "conv64", (1, 1, 1, 256, npx, h8, w8): "corr"}, "events": {}}
+    prof = {"match": {(3, 3, 1, 64, 64, H, W): "conv64", (1, 1, 1, 256, npx, h8, w8): "corr", ("wgrad", 3, 64, 64, H, W): "wgrad64"}, "events": {}}
     net._ops.profile = prof
     eager = optim.TrainStep(net, opt, use_graph=False)
     for _ in range(3):
@@ -245,6 +251,8 @@ def main():
     net._ops.profile = None
 
     def avg_ms(name):
+        """mean of the per-launch HIP-event times of one kernel family (an event pair around a short kernel also times the pair
+        itself: `event_pair_overhead_ms` is reported next to the sub-50-us kernels; rocprofv3's averages are in profiles/)"""
         ev = prof["events"].get(name, [])
         return (sum(s.elapsed_time(e) for s, e in ev) / len(ev), len(ev)) if ev else (None, 0)
 
@@ -274,7 +282,7 @@ def main():
                     "mfma_view": {"achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_BF16_MFMA_TFLOPS, "frac": tf / PEAK_BF16_MFMA_TFLOPS,
                                   "algorithmic_flops_per_launch": flops}}
             try:        # NOT measured in this run: HBM traffic of the same kernels from the committed PMC passes (profiles/)
-                src = "profiles/r02_pmc_summary.json"
+                src = "profiles/r03_pmc_summary.json"
                 pm = json.load(open(os.path.join(ROOT, src)))["kernels"]
                 ks = [v for k, v in pm.items() if k.startswith("conv_rs_bf16_kernel<2, 2, true, 2, 0,")]
                 if (H, W) == (1080, 1920) and ks:
@@ -293,9 +301,19 @@ def main():
         extra["warp2_kernel"] = {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_ms": ms, "launches": nl,
                                  "algorithmic_bytes_per_launch": alg, "event_pair_overhead_ms": ev_overhead_ms}
+    ms, nl = avg_ms("wgrad64")
+    if ms is not None:          # autograd of model.py:60-67's conv: reads the 64-ch input and the 64-ch output gradient once
+        alg = 2 * px * 64 * 2
+        extra["wgrad64_dma_bf16_kernel"] = {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                            "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_ms": ms, "launches": nl,
+                                            "algorithmic_bytes_per_launch": alg,
+                                            "mfma_frac": 2.0 * 9 * 64 * 64 * px / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
     ms, nl = avg_ms("corr")
-    if ms is not None:          # corr.py:52-60: the fp32 all-pairs volume written once (+ both feature maps read)
-        alg = float(npx) * npx * 4 + 2 * npx * 256 * (2 if a.precision == "bf16" else 4)
+    if ms is not None:          # corr.py:13-27, 52-60: the fp32 all-pairs volume and (bf16 mode: same launch) its 3 pooled levels written once, both feature maps read
+        fc = os.environ.get("ZT_FUSED_CORR", "auto")
+        fused = a.precision == "bf16" and (fc == "1" or (fc == "auto" and npx >= 8000))     # zero-tig_amd/raft.py: one launch for volume + pyramid
+        pyr = sum((h8 >> l) * (w8 >> l) for l in (1, 2, 3)) * float(npx) * 4 if fused else 0.0
+        alg = float(npx) * npx * 4 + pyr + 2 * npx * 256 * (2 if a.precision == "bf16" else 4)
         extra["corr_volume"] = {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_ms": ms, "launches": nl,
                                 "algorithmic_bytes_per_launch": alg, "event_pair_overhead_ms": ev_overhead_ms}

@@ -174,9 +174,22 @@ int zt_raft_pack_input(const float* img1, const unsigned char* q2, const int* lu
 int zt_raft_pack_pair(const float* img1, const float* img2, void* dst, int dt, int ld, int h, int w, int Hp, int Wp, zt_stream_t stream);
 /* corr.py:25-27 one pyramid level: avg_pool2d(2,2) of [npx][hin][win] (row pitch ldin) -> [npx][hin/2][win/2] */
 int zt_corr_pool_f32(const float* src, float* dst, int npx, int hin, int win, int ldin, zt_stream_t stream);
+/* corr.py:13-27, 52-60 in one pass, bf16 feature maps: c0[m][y2*w + x2] = alpha * <f1[m], f2[y2*w + x2]> (fp32 [npx][ld0]) and the
+ * three avg_pool2d(2,2) levels c1 [npx][h/2 * w/2], c2, c3 (floor sizes), each from the rounded level below.  f1 / f2: nhwc bf16
+ * [npx][ld >= 256] (256 channels).  Replaces zt_conv2d_nhwc_bf16 (as a 1x1 GEMM) + 3 x zt_corr_pool_f32. */
+int zt_corr_volume_pyramid_bf16(const void* f1, int ld1, const void* f2, int ld2, int h, int w, float alpha, float* c0, int ld0, float* c1,
+                                float* c2, float* c3, zt_stream_t stream);
 /* corr.py:29-50 (the seam of alt_cuda_corr.forward, corr.py:86): coords [npx][2] -> out nhwc [npx][ldo>=324], channel = lvl*81 + i*9 + j */
 int zt_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, int h, int w, int ld0, const float* coords,
                    void* out, int dt, int ldo, int npx, zt_stream_t stream);
+/* The same lookup with the flow bookkeeping of the PREVIOUS refinement iteration folded in (raft.py:112-126: `coords1 = coords1 +
+ * delta_flow` feeds the next iteration's `corr_fn(coords1)`): looks up at coords + delta (delta [npx][ldd] fp32, may be NULL) and
+ * records coords_out = coords + delta (a different buffer than coords), flow = coords_out - grid into f4 (fp32 [npx][ldf4]) and the
+ * nhwc destinations fhx / fin of storage type dt (each may be NULL) -- one launch less per iteration than lookup + zt_raft_flow_step,
+ * bit-identical values. */
+int zt_corr_lookup_step(const float* l0, const float* l1, const float* l2, const float* l3, int h, int w, int ld0, const float* coords,
+                        void* out, int dt, int ldo, int npx, const float* delta, int ldd, float* coords_out, float* f4, int ldf4,
+                        void* fhx, int ldfhx, void* fin, int ldfin, zt_stream_t stream);
 /* update.py:42-45: rh = r*h with zr = [z|r]; update.py:47: h = (1-z)h + z q */
 int zt_gru_rh(const void* zr, int dt, int ldzr, const void* hbuf, int ldh, void* rh, int ldrh, int C, int npx, zt_stream_t stream);
 int zt_gru_update(const void* zr, int dt, int ldzr, const void* q, int ldq, void* hbuf, int ldh, int C, int npx, zt_stream_t stream);
@@ -243,6 +256,13 @@ int zt_probe_mfma_bf16(const unsigned short* A, const unsigned short* B, float* 
 int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin, const void* w,
                         int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout, int KH, int KW, int stride,
                         int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi, zt_stream_t stream);
+/* TWO independent stride-1 convolutions over the same map (square kernels KA / KB in {1, 3, 7}, pad K / 2; bf16 nhwc in and out,
+ * y = act(conv + bias)) in ONE launch: RAFT's motion encoder runs convc1 (1x1, 324 -> 256) next to convf1 (7x7, 2 -> 128) and convc2
+ * (3x3, 256 -> 192) next to convf2 (3x3, 128 -> 64) (update.py:89-94).  Same results as two zt_conv2d_nhwc_bf16 calls (which is what
+ * it falls back to when the two problems do not share a launch shape). */
+int zt_conv2d_pair_nhwc_bf16(const void* xA, int ldxA, int CinA, const void* wA, int CoutPA, int ldkA, const float* biasA, void* yA, int ldyA,
+                             int CoutA, int KA, const void* xB, int ldxB, int CinB, const void* wB, int CoutPB, int ldkB, const float* biasB,
+                             void* yB, int ldyB, int CoutB, int KB, int N, int H, int W, int act, zt_stream_t stream);
 /* same, with the kernel variant pinned (tests / tuning): 0 auto, 1 persistent weight-stationary (stride 1, K in {1,3}, Cin <= 64, N == 1),
  * 2 tiled, 3 register-stationary persistent (3x3, bf16 nhwc output, act in {none, ReLU, LeakyReLU}, exactly 48 or 64 couts) */
 int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin, const void* w,

@@ -331,6 +331,64 @@ def test_raft_ops_golden(backend, oracle, synth):
     assert torch.equal(look2.cpu().permute(0, 3, 1, 2), oracle.corr_lookup(pyr, coords))
 
 
+@pytest.mark.parametrize("pair", [(324, 256, 1, 2, 128, 7), (256, 192, 3, 128, 64, 3), (96, 64, 3, 40, 32, 3)], ids=["1x1+7x7", "3x3+3x3", "fallback"])
+def test_conv_pair_equals_two_launches(backend, pair):
+    """zt_conv2d_pair_nhwc_bf16 (RAFT motion encoder: convc1 || convf1, convc2 || convf2 in one launch each) against the same two
+    convolutions launched separately: the same kernel body runs, so the outputs must be bit-identical (third case: a shape the
+    pair kernels do not cover takes the two-launch fallback)."""
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    CinA, CoutA, KA, CinB, CoutB, KB = pair
+    H, W = 9, 40
+    g = torch.Generator().manual_seed(CinA + KB)
+
+    def mk(Cin, Cout, K):
+        ld = (Cin + 7) // 8 * 8
+        x = torch.zeros(1, H, W, ld)
+        x[..., :Cin] = torch.randn(1, H, W, Cin, generator=g)
+        w = torch.randn(Cout, Cin, K, K, generator=g) * (Cin * K * K) ** -0.5
+        b = torch.randn(Cout, generator=g)
+        return CV(x.bfloat16().to(dev), 0, Cin), ops.repack_weight_bf16(w.to(dev)), b.to(dev)
+    xA, wA, bA = mk(CinA, CoutA, KA)
+    xB, wB, bB = mk(CinB, CoutB, KB)
+    oA = torch.zeros(1, H, W, CoutA, dtype=torch.bfloat16, device=dev)
+    oB = torch.zeros(1, H, W, CoutB + 8, dtype=torch.bfloat16, device=dev)             # a channel slice of a wider buffer
+    ops.conv_pair_bf16(xA, wA, bA, CoutA, KA, oA, xB, wB, bB, CoutB, KB, CV(oB, 8, CoutB), act="relu")
+    rA = ops.conv2d_bf16(xA, wA, bA, CoutA, KA, KA, (KA // 2, KA // 2), "relu")
+    rB = ops.conv2d_bf16(xB, wB, bB, CoutB, KB, KB, (KB // 2, KB // 2), "relu")
+    assert torch.equal(oA.cpu(), rA.cpu()[..., :CoutA]) and torch.equal(oB.cpu()[..., 8:], rB.cpu()[..., :CoutB])
+    assert float(oB.float().abs().max()) > 0 and float(oB[..., :8].float().abs().max()) == 0
+
+
+CORR_SIZES = [pytest.param(18, 40, id="18x40"), pytest.param(16, 32, id="16x32"), pytest.param(45, 80, id="45x80", marks=pytest.mark.gpu),
+              pytest.param(23, 40, id="23x40", marks=pytest.mark.gpu), pytest.param(90, 160, id="90x160", marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("h,w", CORR_SIZES)
+def test_corr_volume_pyramid_fused_bf16(backend, h, w):
+    """corr.py:13-27, 52-60 in one launch (zt_corr.hip): all-pairs volume of two bf16 feature maps / sqrt(256) and the three
+    avg_pool2d(2, 2) levels, against torch on the same bf16-rounded inputs; ragged bands / column tiles / source tiles, floor sizes
+    of the pooled levels (45 -> 22 -> 11 -> 5)."""
+    import torch.nn.functional as F
+    ops, dev, name = backend
+    if name == "emu" and h * w > 1000:
+        pytest.skip("minutes on the emulator")
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    npx = h * w
+    f1 = torch.randn(npx, 256, generator=g).bfloat16()
+    f2 = torch.randn((npx + 15) // 16 * 16, 256, generator=g).bfloat16()
+    f2[npx:] = 0
+    corr0, levels = ops.corr_volume_pyramid_bf16(f1.to(dev), f2.to(dev), h, w, 1.0 / 16.0)
+    ref = (f1.float() @ f2[:npx].float().t()) / 16.0                               # [npx1][npx2]
+    assert maxerr(corr0.view(npx, -1)[:, :npx], ref) < 2e-5 * float(ref.abs().max())
+    lvl = ref.view(npx, 1, h, w)
+    for got in levels:
+        lvl = F.avg_pool2d(lvl, 2, stride=2)
+        assert tuple(got.shape) == (npx, lvl.shape[2], lvl.shape[3])
+        assert maxerr(got, lvl[:, 0]) < 2e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_raft_update_step_golden(backend, oracle, synth, precision):
     """One BasicUpdateBlock step (update.py:114-136) through the plan's HIP kernels -- fused 4-level lookup, motion encoder,

@@ -500,7 +500,7 @@ constexpr int HCK = 32;                 // channel granularity of a two-part (sp
 // MFMA work per chunk (~0.2 us) cannot cover a global latency (~1-2 us): with PD = 3 nearly the whole K range is requested
 // before the first MFMA instead of one latency being exposed per chunk.
 template <int KH, int KW, int S, int NT, int MT, bool ALL, int CH2, int PD>
-__global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
+__device__ __forceinline__ void conv_mfma_bf16_body(const ConvArgsH& a, const int block_y) {
   static_assert(ALL || PD == 1, "per-row weight groups are staged inside the chunk");
   if (a.dbg & 8) return;                                        // tuning ablation (tools/bench_small.py): launch cost only
   constexpr int KCH = 32 * CH2, KCHP = CH2 == 2 ? 80 : 48, CPP = 4 * CH2;      // channels / LDS pitch / 16-byte chunks per pixel
@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
     n = ty / a.tilesY;
     ty -= n * a.tilesY;
   }
-  const int co0 = blockIdx.y * (NT * 16);
+  const int co0 = block_y * (NT * 16);
   const int oy0 = ty * TH, ox0 = tx * TWm;
   const int gy0 = oy0 * S - a.padH, gx0 = ox0 * S - a.padW;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -895,6 +895,28 @@ __global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
       }
     }
   }
+}
+
+template <int KH, int KW, int S, int NT, int MT, bool ALL, int CH2, int PD>
+__global__ void __launch_bounds__(256) conv_mfma_bf16_kernel(ConvArgsH a) {
+  conv_mfma_bf16_body<KH, KW, S, NT, MT, ALL, CH2, PD>(a, (int)blockIdx.y);
+}
+
+// TWO independent convolutions of the same kernel instantiation and the same map in ONE launch: cout groups [0, ysplit) of the
+// grid's y axis run problem a0, the rest a1 (RAFT's motion encoder: convc2 || convf2, update.py:91-94 -- the small-map layers are
+// bound by their fixed launch + prologue + epilogue cost, and neither of the two fills the chip on its own)
+template <int KH, int KW, int S, int NT, int MT, bool ALL, int CH2, int PD>
+__global__ void __launch_bounds__(256) conv_mfma_bf16_pair_kernel(ConvArgsH a0, ConvArgsH a1, int ysplit) {
+  const bool first = (int)blockIdx.y < ysplit;                    // uniform
+  conv_mfma_bf16_body<KH, KW, S, NT, MT, ALL, CH2, PD>(first ? a0 : a1, first ? (int)blockIdx.y : (int)blockIdx.y - ysplit);
+}
+
+// ... and of two DIFFERENT instantiations (same map, 16-pixel tiles): convc1 (1x1, 324 -> 256) || convf1 (7x7, 2 -> 128), the two
+// heads of the motion encoder (update.py:89, 91).  Each body has its own static LDS tile; a workgroup uses one of them.
+template <int KH1, int KW1, int NT1, bool ALL1, int CH21, int PD1, int KH2, int KW2, int NT2, bool ALL2, int CH22, int PD2>
+__global__ void __launch_bounds__(256) conv_mfma_bf16_pair2_kernel(ConvArgsH a0, ConvArgsH a1, int ysplit) {
+  if ((int)blockIdx.y < ysplit) conv_mfma_bf16_body<KH1, KW1, 1, NT1, 1, ALL1, CH21, PD1>(a0, (int)blockIdx.y);
+  else conv_mfma_bf16_body<KH2, KW2, 1, NT2, 1, ALL2, CH22, PD2>(a1, (int)blockIdx.y - ysplit);
 }
 
 template <int KH, int KW, int S, int MT>
@@ -2087,46 +2109,61 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
     ty = band * 4 + r - tx * rows;
   };
 
+  // DMA slot e = 64 (8 i + wave) + lane -> pixel e >> 3 of the tile image (row-major), PHYSICAL 16-byte chunk e & 7, which receives
+  // the logical chunk (e & 7) ^ (s(col) << 1): the swizzle sits on the source address (a DMA destination is lane-linear).  The
+  // slot's source offset relative to the tile origin is tile-invariant: computed once (interior tiles: one 64-bit add per DMA;
+  // the inner loop is VALU-issue bound -- 2.9 VALU per MFMA in the first build of this kernel -- so per-tile index arithmetic counts)
+  int xoff[NGX], zoff[NGZ];
+#pragma unroll
+  for (int i = 0; i < NGX; ++i) {
+    const int e = (i * NW + wave) * 64 + lane;
+    const int p = e >> 3, row = p / IC, col = p - row * IC;
+    xoff[i] = (row * a.W + col) * a.ldx + (((e & 7) ^ (wg64_swz(col) << 1)) * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < NGZ; ++i) {
+    const int e = (i * NW + wave) * 64 + lane;
+    const int p = e >> 3, row = p / HTW, col = p - row * HTW;
+    zoff[i] = (row * a.W + col) * a.lddz + (((e & 7) ^ (wg64_swz(col) << 1)) * 8);
+  }
   auto dma_tile = [&](int idx, int buf) {
     int ty, tx;
     tile_xy(idx, ty, tx);
     const int oy0 = ty * HTH, ox0 = tx * HTW;
     zt_bf16* xb = smem + buf * (WG64_XE + WG64_ZE);
     zt_bf16* zb = xb + WG64_XE;
+    if (oy0 - 1 >= 0 && oy0 - 1 + IR <= a.H && ox0 - 1 >= 0 && ox0 - 1 + IC <= a.W) {      // uniform: interior tile (~95 % at 1080p)
+      const zt_bf16* xo = a.x + (unsigned)(((oy0 - 1) * a.W + ox0 - 1) * a.ldx);
+      const zt_bf16* zo = a.dz + (unsigned)((oy0 * a.W + ox0) * a.lddz);
+#pragma unroll
+      for (int i = 0; i < NGX; ++i)
+        if ((i * NW + NW) * 64 <= IR * IC * 8 || (i * NW + wave) * 64 + lane < IR * IC * 8) ZT_GLDS16_HIDDEN(xo + xoff[i], xb + (i * NW + wave) * 512);
+#pragma unroll
+      for (int i = 0; i < NGZ; ++i) ZT_GLDS16_HIDDEN(zo + zoff[i], zb + (i * NW + wave) * 512);
+      return;
+    }
     int ln = lane;
-    ZT_OPAQUE(ln);                                              // slot geometry recomputed per tile, not kept in registers
-    const bool interior = oy0 - 1 >= 0 && oy0 - 1 + IR <= a.H && ox0 - 1 >= 0 && ox0 - 1 + IC <= a.W;      // uniform
+    ZT_OPAQUE(ln);                                              // border tiles: slot geometry recomputed, out-of-image pixels read zeros
 #pragma unroll
     for (int i = 0; i < NGX; ++i) {
       const int e = (i * NW + wave) * 64 + ln;
       const int p = e >> 3, row = p / IC, col = p - row * IC;
-      const int cj = (e & 7) ^ (wg64_swz(col) << 1);            // logical 16-byte chunk that lands in physical chunk e & 7
+      const int cj = (e & 7) ^ (wg64_swz(col) << 1);
       const int gy = oy0 - 1 + row, gx = ox0 - 1 + col;
-      const void* src;
-      if (interior) {
-        src = a.x + (unsigned)((gy * a.W + gx) * a.ldx + cj * 8);
-      } else {
-        const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const int gyc = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-        src = in ? (const void*)(a.x + (unsigned)((gyc * a.W + gxc) * a.ldx + cj * 8)) : (const void*)&zt_zero_chunk;
-      }
+      const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const int gyc = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+      const void* src = in ? (const void*)(a.x + (unsigned)((gyc * a.W + gxc) * a.ldx + cj * 8)) : (const void*)&zt_zero_chunk;
       if ((i * NW + NW) * 64 <= IR * IC * 8 || e < IR * IC * 8) ZT_GLDS16_HIDDEN(src, xb + (i * NW + wave) * 512);
     }
-    const bool zin = oy0 + HTH <= a.H && ox0 + HTW <= a.W;       // uniform
 #pragma unroll
     for (int i = 0; i < NGZ; ++i) {
       const int e = (i * NW + wave) * 64 + ln;
       const int p = e >> 3, row = p / HTW, col = p - row * HTW;
       const int cj = (e & 7) ^ (wg64_swz(col) << 1);
       const int gy = oy0 + row, gx = ox0 + col;
-      const void* src;
-      if (zin) {
-        src = a.dz + (unsigned)((gy * a.W + gx) * a.lddz + cj * 8);
-      } else {
-        const bool in = gy < a.H && gx < a.W;
-        const int gyc = gy >= a.H ? a.H - 1 : gy, gxc = gx >= a.W ? a.W - 1 : gx;
-        src = in ? (const void*)(a.dz + (unsigned)((gyc * a.W + gxc) * a.lddz + cj * 8)) : (const void*)&zt_zero_chunk;
-      }
+      const bool in = gy < a.H && gx < a.W;
+      const int gyc = gy >= a.H ? a.H - 1 : gy, gxc = gx >= a.W ? a.W - 1 : gx;
+      const void* src = in ? (const void*)(a.dz + (unsigned)((gyc * a.W + gxc) * a.lddz + cj * 8)) : (const void*)&zt_zero_chunk;
       ZT_GLDS16_HIDDEN(src, zb + (i * NW + wave) * 512);
     }
   };
@@ -2155,8 +2192,8 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
     const int c0 = g8 + trq, c1 = c0 + 4;
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
-      blo[q] = c0 * 64 + ((q ^ wg64_swz(c0)) * 16) + trp;
-      bhi[q] = c1 * 64 + ((q ^ wg64_swz(c1)) * 16) + trp;
+      blo[q] = WG64_XE + c0 * 64 + ((q ^ wg64_swz(c0)) * 16) + trp;
+      bhi[q] = WG64_XE + c1 * 64 + ((q ^ wg64_swz(c1)) * 16) + trp;
     }
   }
   const bool ones_slot = wave == 4;                              // uniform: pair slot PPW - 1 of wave 4 = bias column sums
@@ -2167,53 +2204,63 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
   for (int k = 0; k < n_my; ++k) {
     ZT_WAIT_HIDDEN_DMA();             // this wave's pieces of tile k have landed ...
     __syncthreads();                  // ... and so have everyone else's; every wave has left tile k-1's loop (its buffer is free)
+    // (a stagger -- waves 4..7 issuing their DMAs a quarter of the MFMA loop later, under their SIMD partner's MFMAs -- measured
+    // no gain: 144.1 vs 143.9 us, profiles/r03_wgrad64_*; all eight issue at the head of the tile)
     if (k + 1 < n_my) dma_tile(pb + (k + 1) * G, (k + 1) & 1);
-    const zt_bf16* xs = smem + (k & 1) * (WG64_XE + WG64_ZE);
-    const zt_bf16* zs = xs + WG64_XE;
-    // one flat software pipeline over the 8 rows x 5 pair slots (see wgrad_mfma_bf16_kernel): A fragments LA steps ahead, a row's
-    // B fragments one row ahead; indices past the tile's end are clamped (re-reads, results unused)
-    constexpr int RB = 4, NS = RB * PPW, AD = 4, LA = 3;
+    // this tile's per-lane read addresses, once: everything below them is a compile-time row offset (ds_read immediate)
+    const zt_bf16* tb = smem + (k & 1) * (WG64_XE + WG64_ZE);
+    const zt_bf16 *pal[PPW], *pah[PPW], *pbl[NT], *pbh[NT];
+#pragma unroll
+    for (int pi = 0; pi < PPW; ++pi) {
+      pal[pi] = tb + alo[pi];
+      pah[pi] = tb + ahi[pi];
+    }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      pbl[q] = tb + blo[q];
+      pbh[q] = tb + bhi[q];
+    }
+    // ONE flat, fully unrolled software pipeline over the 8 rows x 5 pair slots: A fragments LA steps ahead of the MFMAs that
+    // consume them, a row's B fragments one row ahead; steps past the tile's end re-read the last row (results unused)
+    constexpr int NS = HTH * PPW, AD = 4, LA = 3;
     zt_s16x4 fal[AD], fah[AD];
     zt_s16x8 bv[2][NT];
-    auto load_a = [&](auto bc, int row, auto pc) {
+    auto load_a = [&](auto bc, auto rc, auto pc) {
       constexpr int bi = decltype(bc)::value, pi = decltype(pc)::value;
-      const zt_bf16* xr = xs + (row < HTH ? row : HTH - 1) * IC * 64;
-      fal[bi] = zt_lds_read_tr16(xr + alo[pi]);
-      fah[bi] = zt_lds_read_tr16(xr + ahi[pi]);
+      constexpr int row = decltype(rc)::value < HTH ? decltype(rc)::value : HTH - 1;
+      fal[bi] = zt_lds_read_tr16(pal[pi] + row * IC * 64);
+      fah[bi] = zt_lds_read_tr16(pah[pi] + row * IC * 64);
     };
-    auto load_b = [&](auto bc, int row) {
+    auto load_b = [&](auto bc, auto rc) {
       constexpr int bi = decltype(bc)::value;
-      const zt_bf16* zr = zs + (row < HTH ? row : HTH - 1) * HTW * 64;
+      constexpr int row = decltype(rc)::value < HTH ? decltype(rc)::value : HTH - 1;
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
-        const zt_s16x4 lo = zt_lds_read_tr16(zr + blo[q]);
-        const zt_s16x4 hi = zt_lds_read_tr16(zr + bhi[q]);
+        const zt_s16x4 lo = zt_lds_read_tr16(pbl[q] + row * HTW * 64);
+        const zt_s16x4 hi = zt_lds_read_tr16(pbh[q] + row * HTW * 64);
         bv[bi][q] = (zt_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     };
-    load_b(ZtIdx<0>{}, 0);
+    load_b(ZtIdx<0>{}, ZtIdx<0>{});
     zt_static_for<0, LA>([&](auto sc) {
       constexpr int st = decltype(sc)::value;
-      load_a(ZtIdx<st % AD>{}, st / PPW, ZtIdx<st % PPW>{});
+      load_a(ZtIdx<st % AD>{}, ZtIdx<st / PPW>{}, ZtIdx<st % PPW>{});
     });
-#pragma unroll 1
-    for (int r0 = 0; r0 < HTH; r0 += RB) {
-      zt_static_for<0, NS>([&](auto sc) {
-        constexpr int st = decltype(sc)::value;
-        constexpr int rl = st / PPW, pi = st % PPW, cur = st % AD;
-        if constexpr (pi == 0) load_b(ZtIdx<(rl + 1) & 1>{}, r0 + rl + 1);
-        {
-          constexpr int nx = st + LA;
-          load_a(ZtIdx<nx % AD>{}, r0 + nx / PPW, ZtIdx<nx % PPW>{});
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        zt_s16x8 av = (zt_s16x8){fal[cur][0], fal[cur][1], fal[cur][2], fal[cur][3], fah[cur][0], fah[cur][1], fah[cur][2], fah[cur][3]};
-        if constexpr (pi == PPW - 1) av = ones_slot ? ones : av;
+    zt_static_for<0, NS>([&](auto sc) {
+      constexpr int st = decltype(sc)::value;
+      constexpr int row = st / PPW, pi = st % PPW, cur = st % AD;
+      if constexpr (pi == 0) load_b(ZtIdx<(row + 1) & 1>{}, ZtIdx<row + 1>{});
+      {
+        constexpr int nx = st + LA;
+        load_a(ZtIdx<nx % AD>{}, ZtIdx<nx / PPW>{}, ZtIdx<nx % PPW>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      zt_s16x8 av = (zt_s16x8){fal[cur][0], fal[cur][1], fal[cur][2], fal[cur][3], fah[cur][0], fah[cur][1], fah[cur][2], fah[cur][3]};
+      if constexpr (pi == PPW - 1) av = ones_slot ? ones : av;
 #pragma unroll
-        for (int q = 0; q < NT; ++q) acc[pi][q] = zt_mfma_bf16(av, bv[rl & 1][q], acc[pi][q]);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    }
+      for (int q = 0; q < NT; ++q) acc[pi][q] = zt_mfma_bf16(av, bv[row & 1][q], acc[pi][q]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
   // slab of this workgroup: [tap][ci 64][co 64] + [co 64] (same layout as wgrad_mfma_bf16_kernel)
   float* out = a.slab + (size_t)blockIdx.x * (9 * 64 * 64 + 64);
@@ -2479,6 +2526,53 @@ static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, 
   ZT_GEO(3, 3, 1) ZT_GEO(3, 3, 2) ZT_GEO(1, 1, 1) ZT_GEO(1, 1, 2) ZT_GEO(1, 5, 1) ZT_GEO(5, 1, 1) ZT_GEO(7, 7, 1) ZT_GEO(7, 7, 2)
 #undef ZT_GEO
   if (rc) return rc;
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+// motion-encoder pairs (see conv_mfma_bf16_pair_kernel / _pair2_kernel): square kernels KA, KB (pad K / 2, stride 1), bf16 nhwc in / out,
+// same map and activation.  Falls back to two launches when the two problems do not take the kernel instantiations built here.
+extern "C" int zt_conv2d_pair_nhwc_bf16(const void* xA, int ldxA, int CinA, const void* wA, int CoutPA, int ldkA, const float* biasA, void* yA,
+                                        int ldyA, int CoutA, int KA, const void* xB, int ldxB, int CinB, const void* wB, int CoutPB, int ldkB,
+                                        const float* biasB, void* yB, int ldyB, int CoutB, int KB, int N, int H, int W, int act, hipStream_t stream) {
+  static const int off = getenv("ZT_RAFT_PAIR") ? !atoi(getenv("ZT_RAFT_PAIR")) : 0;     // A/B knob: ZT_RAFT_PAIR=0 -> two launches
+  auto single = [&]() {
+    int rc = conv2d_bf16_impl(xA, nullptr, 0, ldxA, 0, N, H, W, CinA, wA, CoutPA, ldkA, biasA, yA, ldyA, 0, CoutA, KA, KA, 1, KA / 2, KA / 2, act, 1.f,
+                              nullptr, 0, 0, 0, nullptr, 0, 0, stream);
+    if (rc) return rc;
+    return conv2d_bf16_impl(xB, nullptr, 0, ldxB, 0, N, H, W, CinB, wB, CoutPB, ldkB, biasB, yB, ldyB, 0, CoutB, KB, KB, 1, KB / 2, KB / 2, act, 1.f,
+                            nullptr, 0, 0, 0, nullptr, 0, 0, stream);
+  };
+  ZT_REQUIRE(xA && xB && wA && wB && yA && yB);
+  const int tilesY = zt_cdiv(H, TH), tilesX = zt_cdiv(W, 16);
+  const int gA = zt_cdiv(zt_cdiv(CoutA, 16), 2), gB = zt_cdiv(zt_cdiv(CoutB, 16), 2);
+  // common conditions of the small-map instantiations (conv2d_bf16_impl / launch_conv_h): NT = 2 (32 couts per workgroup), MT = 1
+  const bool small = !off && N == 1 && CoutA % 32 == 0 && CoutB % 32 == 0 && CoutA >= 64 && CoutB >= 64 &&
+                     (long long)zt_cdiv(W, 32) * tilesY * zt_cdiv(CoutA / 16, 2) < 512 && (long long)zt_cdiv(W, 32) * tilesY * zt_cdiv(CoutB / 16, 2) < 512 &&
+                     (long long)tilesX * tilesY * (gA + gB) <= 1024 && ldxA % 8 == 0 && ldxB % 8 == 0 && ldyA % 8 == 0 && ldyB % 8 == 0 && tilesY <= 65535;
+  // (3x3, 3x3): both wide (64-channel chunks) and deep (two chunks in flight); (1x1, 7x7): 32-channel chunks, 1x1 deep, 7x7 per-row weights
+  const bool p33 = small && KA == 3 && KB == 3 && CinA % 64 == 0 && CinB % 64 == 0 && CinA > 64 && CinB > 64;
+  const bool p17 = small && KA == 1 && KB == 7 && CinA % 64 != 0 && CinA > 64 && CinB <= 8;
+  if (!p33 && !p17) return single();
+  ConvArgsH a[2];
+  const void* xs[2] = {xA, xB};
+  const void* ws[2] = {wA, wB};
+  const float* bs[2] = {biasA, biasB};
+  void* ys[2] = {yA, yB};
+  const int ldx[2] = {ldxA, ldxB}, Cin[2] = {CinA, CinB}, CoutP[2] = {CoutPA, CoutPB}, ldk[2] = {ldkA, ldkB}, ldy[2] = {ldyA, ldyB}, Cout[2] = {CoutA, CoutB};
+  const int Ks[2] = {KA, KB};
+  for (int i = 0; i < 2; ++i) {
+    ConvArgsH& c = a[i];
+    c.x = (const zt_bf16*)xs[i]; c.x2 = nullptr; c.w = (const zt_bf16*)ws[i]; c.bias = bs[i]; c.aux = nullptr; c.y = ys[i];
+    c.N = N; c.H = H; c.W = W; c.Cin = Cin[i]; c.ldx = ldx[i]; c.ldx2 = 0; c.csplit = 0;
+    c.Ho = H; c.Wo = W; c.Cout = Cout[i]; c.CoutP = CoutP[i]; c.ldk = ldk[i]; c.ldy = ldy[i]; c.ldaux = 0;
+    c.padH = Ks[i] / 2; c.padW = Ks[i] / 2; c.act = act; c.epi = 0; c.out_mode = 0; c.dbg = 0; c.alpha = 1.f;
+    c.tilesX = tilesX; c.tilesY = tilesY; c.y2 = nullptr; c.ldy2 = 0; c.esplit = 0; c.stats = nullptr;
+    ZT_REQUIRE(((uintptr_t)c.x & 15) == 0 && ((uintptr_t)c.w & 15) == 0 && c.ldk % 8 == 0 && ((uintptr_t)c.y & 15) == 0);
+  }
+  const dim3 grid(tilesX, gA + gB, tilesY);
+  if (p33) hipLaunchKernelGGL((conv_mfma_bf16_pair_kernel<3, 3, 1, 2, 1, true, 2, 2>), grid, dim3(256), 0, stream, a[0], a[1], gA);
+  else hipLaunchKernelGGL((conv_mfma_bf16_pair2_kernel<1, 1, 2, true, 1, 2, 7, 7, 2, false, 1, 1>), grid, dim3(256), 0, stream, a[0], a[1], gA);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

@@ -163,6 +163,15 @@ struct LookupArgs {
   const float* coords;      // [npx][2] (x, y)
   void* out;                // [npx][ldo], fp32 or bf16
   int npx, ldo;
+  // fused flow bookkeeping of the PREVIOUS refinement iteration (raft.py:112-120; zt_corr_lookup_step): the coordinates looked up
+  // are coords + delta, written to coords_out (a different buffer: other threads of the pixel still read coords) together with
+  // flow = coords_out - grid for the up-sampler (f4, fp32) and the two nhwc consumers of the same iteration (fhx, fin; type T)
+  const float* delta;
+  float* coords_out;
+  float* f4;
+  void* fhx;
+  void* fin;
+  int ldd, ldf4, ldfhx, ldfin, w0;
 };
 
 // corr.py:29-50 + utils.py:285-299: 4 levels x 9x9 window, bilinear, align_corners=True, zeros padding.
@@ -176,8 +185,30 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(LookupArgs a) {
   int l = ch / 81, r = ch - l * 81;
   int i = r / 9, j = r - i * 9;
   const int H = a.h[l], W = a.w[l];
-  float cx = a.coords[n * 2 + 0] / (float)(1 << l) + (float)(i - 4);
-  float cy = a.coords[n * 2 + 1] / (float)(1 << l) + (float)(j - 4);
+  float px = a.coords[n * 2 + 0], py = a.coords[n * 2 + 1];
+  if (a.delta) {                                                  // same fp32 add as flow_step_kernel: results are bit-identical
+    px += a.delta[(size_t)n * a.ldd + 0];
+    py += a.delta[(size_t)n * a.ldd + 1];
+  }
+  if (ch == 0 && a.coords_out) {
+    a.coords_out[n * 2 + 0] = px;
+    a.coords_out[n * 2 + 1] = py;
+    const float fx = px - (float)(n % a.w0), fy = py - (float)(n / a.w0);
+    if (a.f4) {
+      a.f4[(size_t)n * a.ldf4 + 0] = fx;
+      a.f4[(size_t)n * a.ldf4 + 1] = fy;
+    }
+    if (a.fhx) {
+      ZtIO<T>::st((T*)a.fhx + (size_t)n * a.ldfhx + 0, fx);
+      ZtIO<T>::st((T*)a.fhx + (size_t)n * a.ldfhx + 1, fy);
+    }
+    if (a.fin) {
+      ZtIO<T>::st((T*)a.fin + (size_t)n * a.ldfin + 0, fx);
+      ZtIO<T>::st((T*)a.fin + (size_t)n * a.ldfin + 1, fy);
+    }
+  }
+  float cx = px / (float)(1 << l) + (float)(i - 4);
+  float cy = py / (float)(1 << l) + (float)(j - 4);
   float gx = 2.f * cx / (float)(W - 1) - 1.f;
   float gy = 2.f * cy / (float)(H - 1) - 1.f;
   float ix = (gx + 1.f) * ((float)(W - 1) / 2.f);
@@ -355,10 +386,15 @@ extern "C" int zt_corr_pool_f32(const float* src, float* dst, int npx, int hin, 
   return ZT_OK;
 }
 
-extern "C" int zt_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, int h, int w, int ld0,
-                              const float* coords, void* out, int dt, int ldo, int npx, hipStream_t stream) {
+extern "C" int zt_corr_lookup_step(const float* l0, const float* l1, const float* l2, const float* l3, int h, int w, int ld0,
+                                   const float* coords, void* out, int dt, int ldo, int npx, const float* delta, int ldd, float* coords_out,
+                                   float* f4, int ldf4, void* fhx, int ldfhx, void* fin, int ldfin, hipStream_t stream) {
   ZT_REQUIRE(l0 && l1 && l2 && l3 && coords && out && ldo >= 324);
+  ZT_REQUIRE(!coords_out || coords_out != coords);
+  ZT_REQUIRE(!delta || coords_out);                 // a delta that is looked up but not recorded would be lost
   LookupArgs a;
+  a.delta = delta; a.ldd = ldd; a.coords_out = coords_out; a.f4 = f4; a.ldf4 = ldf4; a.fhx = fhx; a.ldfhx = ldfhx; a.fin = fin;
+  a.ldfin = ldfin; a.w0 = w;
   a.lvl[0] = l0; a.lvl[1] = l1; a.lvl[2] = l2; a.lvl[3] = l3;
   int hh = h, ww = w;
   for (int l = 0; l < 4; ++l) {
@@ -372,6 +408,11 @@ extern "C" int zt_corr_lookup(const float* l0, const float* l1, const float* l2,
   else hipLaunchKernelGGL(corr_lookup_kernel<zt_bf16>, dim3((unsigned)zt_cdivl(total, 256)), dim3(256), 0, stream, a);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
+}
+
+extern "C" int zt_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, int h, int w, int ld0,
+                              const float* coords, void* out, int dt, int ldo, int npx, hipStream_t stream) {
+  return zt_corr_lookup_step(l0, l1, l2, l3, h, w, ld0, coords, out, dt, ldo, npx, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, stream);
 }
 
 extern "C" int zt_gru_rh(const void* zr, int dt, int ldzr, const void* hbuf, int ldh, void* rh, int ldrh, int C, int npx,

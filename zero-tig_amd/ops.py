@@ -431,12 +431,34 @@ class Ops:
             ldin = hin * win
         return levels
 
+    def corr_volume_pyramid_bf16(self, fmap1, fmap2, h, w, alpha):
+        """fmap1 / fmap2: bf16 [.., 256]-channel NHWC feature maps of the two frames ([npx][ld] views) -> (corr0 [1,h,w,ld0] fp32,
+        [level1, level2, level3]) in one launch (corr.py:13-27, 52-60)."""
+        npx = h * w
+        ld0 = (npx + 3) // 4 * 4
+        dev = fmap1.device
+        corr0 = torch.empty((1, h, w, ld0), dtype=torch.float32, device=dev)
+        dims = [(h // 2, w // 2), (h // 4, w // 4), (h // 8, w // 8)]
+        levels = [torch.empty((npx, a, b), dtype=torch.float32, device=dev) for a, b in dims]
+        tok = self._ev_begin(self.profile["match"].get((1, 1, 1, 256, npx, h, w))) if self.profile else None
+        self.lib.call("zt_corr_volume_pyramid_bf16", fmap1, fmap1.shape[-1], fmap2, fmap2.shape[-1], h, w, float(alpha), corr0, ld0,
+                      levels[0], levels[1], levels[2], self._s(fmap1))
+        self._ev_end(tok)
+        return corr0, levels
+
     def corr_lookup(self, corr0, levels, h, w, coords, out=None):
         npx = h * w
         if out is None:
             out = torch.empty((1, h, w, 324), dtype=torch.float32, device=corr0.device)
         self.lib.call("zt_corr_lookup", corr0, levels[0], levels[1], levels[2], h, w, corr0.shape[-1], coords, out, _dt(out),
                       out.shape[-1], npx, self._s(corr0))
+        return out
+
+    def corr_lookup_step(self, corr0, levels, h, w, coords, out, delta, coords_out, f4, fhx_ptr, ldfhx, fin):
+        """lookup at coords + delta with the previous iteration's flow bookkeeping folded in (zt_corr_lookup_step)."""
+        self.lib.call("zt_corr_lookup_step", corr0, levels[0], levels[1], levels[2], h, w, corr0.shape[-1], coords, out, _dt(out),
+                      out.shape[-1], h * w, delta, 0 if delta is None else delta.shape[-1], coords_out, f4, f4.shape[-1], fhx_ptr, ldfhx,
+                      fin, fin.shape[-1], self._s(corr0))
         return out
 
     # ---- bf16 throughput mode of the convolution family ---------------------------------------------------------
@@ -503,6 +525,16 @@ class Ops:
         self._ev_end(tok)
         return out
 
+    def conv_pair_bf16(self, xA, wA, bA, CoutA, KA, outA, xB, wB, bB, CoutB, KB, outB, act=None):
+        """Two independent stride-1 'same' convolutions (square kernels KA / KB) over the same map in ONE launch
+        (zt_conv2d_pair_nhwc_bf16): bf16 NHWC in and out, y = act(conv + bias)."""
+        xA, xB, oA, oB = _cv(xA), _cv(xB), _cv(outA), _cv(outB)
+        assert (xA.N, xA.H, xA.W) == (xB.N, xB.H, xB.W) == (oA.N, oA.H, oA.W) == (oB.N, oB.H, oB.W)
+        assert all(t.t.dtype == torch.bfloat16 for t in (xA, xB, oA, oB)) and wA.shape[0] == KA * KA and wB.shape[0] == KB * KB
+        assert wA.shape[2] >= xA.C and wB.shape[2] >= xB.C and wA.shape[1] >= CoutA and wB.shape[1] >= CoutB and oA.C >= CoutA and oB.C >= CoutB
+        self.lib.call("zt_conv2d_pair_nhwc_bf16", xA.ptr, xA.ld, xA.C, wA, wA.shape[1], wA.shape[2], bA, oA.ptr, oA.ld, CoutA, KA,
+                      xB.ptr, xB.ld, xB.C, wB, wB.shape[1], wB.shape[2], bB, oB.ptr, oB.ld, CoutB, KB, xA.N, xA.H, xA.W, ACT[act], self._s(xA.t))
+
     # ---- deferred, batched weight gradients / weight repacks (bf16 mode) -----------------------------------------------
     def wgrad_partial_bf16(self, x, dz, Cout, K, slab, slab_off, relu_mask=None):
         """Append the per-workgroup slabs of one weight-gradient call to `slab` (fp32 tensor) at float offset slab_off.
@@ -512,8 +544,10 @@ class Ops:
         assert x.t.dtype == torch.bfloat16 and dz.t.dtype == torch.bfloat16 and x.N == 1 and (x.H, x.W) == (dz.H, dz.W) and dz.C >= Cout
         mk = _cv(relu_mask) if relu_mask is not None else None
         n = ctypes.c_int(0)
+        tok = self._ev_begin(self.profile["match"].get(("wgrad", K, x.C, Cout, x.H, x.W))) if self.profile else None
         self.lib.call("zt_conv2d_wgrad_partial_bf16", x.ptr, x.ld, dz.ptr, dz.ld, x.H, x.W, x.C, Cout, K, K, slab.data_ptr() + 4 * slab_off,
                       (slab.numel() - slab_off) * 4, mk.ptr if mk else None, mk.ld if mk else 0, ctypes.byref(n), self._s(x.t))
+        self._ev_end(tok)
         return n.value
 
     @staticmethod

@@ -14,6 +14,11 @@ from .ops import CV
 
 
 _ONE_LAUNCH_IN = os.environ.get("ZT_INSTNORM_ONE_LAUNCH", "0") == "1"
+# Correlation volume + its three pooled levels in one launch (csrc/zt_corr.hip) or as the tiled GEMM + three pooling launches.
+# Measured (gpurun_out/r03f): 1080p (3 600 x 3 600 volume, 68 MB with the pyramid) 54 us fused vs 29 + 3 x 7.5 = 51.5 us -- the
+# fused kernel's four DMA -> barrier -> 32-MFMA phases per workgroup are latency-bound at that size; 4K (14 400^2, 1.1 GB) 0.53 ms
+# fused vs 0.39 + 3 x 0.087 = 0.65 ms.  "auto" = fused from 8 000 map pixels up; ZT_FUSED_CORR=1 / 0 force either.
+_FUSED_CORR = os.environ.get("ZT_FUSED_CORR", "auto")
 
 class _Side:
     """`with plan._side():` runs the enclosed launches on a second HIP stream, forked from / joined back into the current one
@@ -188,13 +193,17 @@ class RaftPlan:
             npxp = (npx + 15) // 16 * 16
             fmap2 = self._new(npxp, 256, zero=True)                         # nhwc == the bf16 weight layout [CoutP][ldk]
             self._conv(CV(f[1:2]), "fnet.conv2", 256, 1, out=fmap2[:npx].view(1, h, w, 256))
-            corr0 = o.conv2d_bf16(CV(fmap1), fmap2.view(1, npxp, 256), None, npx, 1, 1, alpha=1.0 / 16.0, out_f32=True)
+            if h >= 16 and w >= 16 and (_FUSED_CORR == "1" or (_FUSED_CORR == "auto" and npx >= 8000)):
+                corr0, levels = o.corr_volume_pyramid_bf16(fmap1.view(npx, 256), fmap2, h, w, 1.0 / 16.0)
+            else:
+                corr0 = o.conv2d_bf16(CV(fmap1), fmap2.view(1, npxp, 256), None, npx, 1, 1, alpha=1.0 / 16.0, out_f32=True)
+                levels = o.corr_pyramid(corr0, h, w)
         else:
             pitch = (npx + 15) // 16 * 16
             fmap2 = self._new(1, 256, pitch, zero=True)
             o.conv2d(CV(f[1:2]), self.wd["fnet.conv2"], self._w("fnet.conv2.bias"), 256, 1, 1, out=fmap2, out_planar=True)
             corr0 = o.conv2d(CV(fmap1), fmap2, None, npx, 1, 1, alpha=1.0 / 16.0)      # corr.py:52-60: / sqrt(256)
-        levels = o.corr_pyramid(corr0, h, w)
+            levels = o.corr_pyramid(corr0, h, w)
         self._join()
         st = self.new_state(h, w, HX)
         st.corr0, st.levels = corr0, levels
@@ -231,7 +240,10 @@ class RaftPlan:
             delta[:, :2] = coords.to(self.dev) - st.coords1
             ldd = 4
         lib.call("zt_raft_flow_step", st.coords1, delta, ldd, h, w, st.F4, 4, HX.data_ptr() + st.es * 382, 384, st.FIN, st.ldfin, dt, s)
+        st.coords2 = torch.empty_like(st.coords1)                            # ping-pong partner (the lookup applies the pending delta)
+        st.pending = False                                                   # a flow-head delta not yet added to coords1
         st.CF, st.RH, st.ZR = self._new(1, h, w, 256), self._new(1, h, w, 128), self._new(1, h, w, 256)
+        st.C1, st.F1 = self._new(1, h, w, 256), self._new(1, h, w, 128)      # convc1 / convf1 outputs (re-used every iteration)
         st.CORR = self._new(1, h, w, 328 if self.h else 324, zero=True)
         st.delta = self._new(1, h, w, 4, dtype=torch.float32, zero=True) if self.h else None   # flow-head output, reused every iteration
         return st
@@ -243,11 +255,24 @@ class RaftPlan:
         e, g = "update_block.encoder.", "update_block.gru."
         # (the two halves of the motion encoder are independent too, but a fork / join per iteration costs more than the overlap
         # of two ~20 us branches returns: +6 us per iteration measured with tools/bench_raft.py)
-        o.corr_lookup(st.corr0, st.levels, h, w, st.coords1, out=CORR)
-        cor1 = self._conv(CV(CORR, 0, 324), e + "convc1", 256, 1, act="relu")
-        self._conv(cor1, e + "convc2", 192, 3, act="relu", out=CV(CF, 0, 192))
-        flo1 = self._conv(CV(st.FIN, 0, 2), e + "convf1", 128, 7, act="relu")
-        self._conv(flo1, e + "convf2", 64, 3, act="relu", out=CV(CF, 192, 64))
+        if st.pending:
+            # the previous iteration's `coords1 += delta_flow` (raft.py:120) rides in this iteration's lookup: it reads coords1 + delta
+            # and records the sum (ping-pong buffer) and the flow for the up-sampler / the 7x7 conv / the GRU input, all of which
+            # are consumed later in this iteration -- one launch less per iteration than a separate zt_raft_flow_step
+            o.corr_lookup_step(st.corr0, st.levels, h, w, st.coords1, CORR, st.delta, st.coords2, st.F4, HX.data_ptr() + st.es * 382, 384, st.FIN)
+            st.coords1, st.coords2, st.pending = st.coords2, st.coords1, False
+        else:
+            o.corr_lookup(st.corr0, st.levels, h, w, st.coords1, out=CORR)
+        if self.h:      # bf16 mode: the two branches of the motion encoder (update.py:89-94) are independent -> two launches, not four
+            o.conv_pair_bf16(CV(CORR, 0, 324), self.wd[e + "convc1"], self._w(e + "convc1.bias"), 256, 1, st.C1,
+                             CV(st.FIN, 0, 2), self.wd[e + "convf1"], self._w(e + "convf1.bias"), 128, 7, st.F1, act="relu")
+            o.conv_pair_bf16(st.C1, self.wd[e + "convc2"], self._w(e + "convc2.bias"), 192, 3, CV(CF, 0, 192),
+                             st.F1, self.wd[e + "convf2"], self._w(e + "convf2.bias"), 64, 3, CV(CF, 192, 64), act="relu")
+        else:
+            cor1 = self._conv(CV(CORR, 0, 324), e + "convc1", 256, 1, act="relu")
+            flo1 = self._conv(CV(st.FIN, 0, 2), e + "convf1", 128, 7, act="relu")
+            self._conv(cor1, e + "convc2", 192, 3, act="relu", out=CV(CF, 0, 192))
+            self._conv(flo1, e + "convf2", 64, 3, act="relu", out=CV(CF, 192, 64))
         self._conv(CF, e + "conv", 126, 3, act="relu", out=CV(HX, 256, 126))
         for sfx, k, pad in (("1", (1, 5), (0, 2)), ("2", (5, 1), (2, 0))):
             # z, r = sigmoid(conv[h | x]) with r * h formed in the epilogue; q = tanh(conv[r*h | x]) with the state update
@@ -257,12 +282,19 @@ class RaftPlan:
                        aux=CV(st.ZR, 0, 128), epi=5)
         fh = self._conv(CV(HX, 0, 128), "update_block.flow_head.conv1", 256, 3, act="relu")
         st.delta = self._conv(fh, "update_block.flow_head.conv2", 2, 3, out_f32=True, out=st.delta)       # fp32 [..,4]
-        lib.call("zt_raft_flow_step", st.coords1, st.delta, st.delta.shape[-1], h, w, st.F4, 4, HX.data_ptr() + st.es * 382, 384,
-                 st.FIN, st.ldfin, dt, s)
+        st.pending = True
+
+    def flush_flow(self, st):
+        """apply a pending flow-head delta (after the last iteration, or when a test inspects the state between iterations)"""
+        if st.pending:
+            self.lib.call("zt_raft_flow_step", st.coords1, st.delta, st.delta.shape[-1], st.h, st.w, st.F4, 4,
+                          st.HX.data_ptr() + st.es * 382, 384, st.FIN, st.ldfin, self.dt, current_stream(self.dev))
+            st.pending = False
 
     def finish(self, st, Hp, Wp):
         """mask head (update.py:122-125, 134) on the final hidden state + convex 8x up-sampling (raft.py:64-75)."""
         HX, h, w = st.HX, st.h, st.w
+        self.flush_flow(st)
         m1 = self._conv(CV(HX, 0, 128), "update_block.mask.0", 256, 3, act="relu")
         mask = self._conv(m1, "update_block.mask.2", 576, 1, alpha=0.25, out_f32=True)
         flow_up = self._new(1, 2, Hp, Wp, dtype=torch.float32)
