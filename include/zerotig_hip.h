@@ -149,9 +149,10 @@ int zt_add3_f32(const float* a, const float* b, const float* c, float* out, long
 int zt_plane_sums_f32(const float* x, int C, long long HW, int nblk, float* partial, zt_stream_t stream);
 /* loss.py:26-37: scal[0..2] = clamp(enhancement_factor,1,25), scal[3..5] = 0.7^-ef / ef */
 int zt_loss_scalars_f32(const float* partial, int nblk, long long HW, int is_WB, float* scal, zt_stream_t stream);
-/* loss.py:46-49 (700 MSE, 1000 MSE, 5 SmoothLoss, 1600 L_TV): partial[block][4] + direct d/ds2 */
+/* loss.py:46-49 (700 MSE, 1000 MSE, 5 SmoothLoss, 1600 L_TV): partial[block][4] + direct d/ds2.  fast_exp: 1 = hardware exponential for
+ * the bilateral weights (bf16 throughput mode), 0 = libm expf (fp32 parity mode) */
 int zt_loss_s2_f32(const float* L2, const float* s2, const float* Y, const float* scal, int H, int W, float* ds2, float* partial,
-                   zt_stream_t stream);
+                   int fast_exp, zt_stream_t stream);
 /* loss.py:51-62, 68-73: partial[block][10] = res1_a..d, res2_a..d, inter_a, inter_b; direct gradients; u1/u2 = (1-m)*de (to be LocalMean-adjointed) */
 int zt_loss_half_f32(const float* Lq11, const float* Lq12, const float* Lp1, const float* Lp2, const float* den1, const float* den2,
                      const float* H3p, const float* H4p, const float* H11, const float* s21, const float* H12, const float* s22,

@@ -1617,23 +1617,21 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
     }
     if constexpr (STATS) {
       // chunk e = tid + NTHR i has channel octet tid % 8 for every i: lanes l, l^8, l^16, l^32 of a wave share it
+      // Reduce-scatter over those 8 lanes instead of a full butterfly: every stage hands HALF of the still-live values to the
+      // partner and keeps the sums of the other half (8 + 4 + 2 = 14 cross-lane moves instead of 48); each lane ends up owning 2 of
+      // the octet's 16 sums -- index 8 (lane>>5 & 1) + 4 (lane>>4 & 1) + 2 (lane>>3 & 1) + {0, 1} -- and adds them to its own two
+      // slots of the per-wave table (fixed order: bit-reproducible).
+      const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+      float k8[8], k4[4], k2[2];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        ssum[c] += __shfl_xor(ssum[c], 8);
-        ssq[c] += __shfl_xor(ssq[c], 8);
-        ssum[c] += __shfl_xor(ssum[c], 16);
-        ssq[c] += __shfl_xor(ssq[c], 16);
-        ssum[c] += __shfl_xor(ssum[c], 32);
-        ssq[c] += __shfl_xor(ssq[c], 32);
-      }
-      if (lane < 8) {                                           // lane owns octet `lane` of this wave's table
-        float* t = stat_s + (wave * CH8 + lane) * 16;
+      for (int c = 0; c < 8; ++c) k8[c] = (h5 ? ssq[c] : ssum[c]) + __shfl_xor(h5 ? ssum[c] : ssq[c], 32);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          t[c] += ssum[c];
-          t[8 + c] += ssq[c];
-        }
-      }
+      for (int c = 0; c < 4; ++c) k4[c] = (h4 ? k8[c + 4] : k8[c]) + __shfl_xor(h4 ? k8[c] : k8[c + 4], 16);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) k2[c] = (h3 ? k4[c + 2] : k4[c]) + __shfl_xor(h3 ? k4[c] : k4[c + 2], 8);
+      float* t = stat_s + (wave * CH8 + (lane & 7)) * 16 + (h5 ? 8 : 0) + (h4 ? 4 : 0) + (h3 ? 2 : 0);
+      t[0] += k2[0];
+      t[1] += k2[1];
     }
   };
 

@@ -83,6 +83,9 @@ struct SmoothCoef {
 // at 0.7 TB/s of its 100 MB).  Per-pixel arithmetic and its order are unchanged.
 constexpr int LS_TX = 64, LS_TY = 16, LS_HALO = 2, LS_PW = LS_TX + 2 * LS_HALO, LS_PH = LS_TY + 2 * LS_HALO;
 
+// FAST (bf16 throughput mode): the 24 bilateral weights per pixel use the hardware exponential (__expf: v_exp_f32 of x log2 e,
+// ~1e-7 relative for these |x| < 1) instead of libm's ~10-instruction expansion -- the kernel is bound by vector-instruction issue
+template <bool FAST>
 __global__ void __launch_bounds__(256) loss_s2_kernel(const float* __restrict__ L2, const float* __restrict__ s2,
                                                       const float* __restrict__ Y, const float* __restrict__ scal, int H,
                                                       int W, float* __restrict__ ds2, float* __restrict__ partial, int nrow4, SmoothCoef sc) {
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(256) loss_s2_kernel(const float* __restrict__ 
             a += fabsf(ds);
             sg[c] = ds > 0.f ? 1.f : (ds < 0.f ? -1.f : 0.f);
           }
-          float wgt = expf(e * -0.005f) * coef;
+          float wgt = (FAST ? __expf(e * -0.005f) : expf(e * -0.005f)) * coef;
           t[2] += wgt * a;
 #pragma unroll
           for (int c = 0; c < 3; ++c) g[c] += wgt * sg[c];
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(256) loss_s2_kernel(const float* __restrict__ 
             float ds = sq[c] - sS[c][ly - dy][lx - dx];
             sg[c] = ds > 0.f ? 1.f : (ds < 0.f ? -1.f : 0.f);
           }
-          float wgt = expf(e * -0.005f) * coef;
+          float wgt = (FAST ? __expf(e * -0.005f) : expf(e * -0.005f)) * coef;
 #pragma unroll
           for (int c = 0; c < 3; ++c) g[c] += wgt * sg[c];
         }
@@ -304,15 +307,16 @@ extern "C" int zt_loss_scalars_f32(const float* partial, int nblk, long long HW,
 }
 
 extern "C" int zt_loss_s2_f32(const float* L2, const float* s2, const float* Y, const float* scal, int H, int W, float* ds2,
-                              float* partial, hipStream_t stream) {
+                              float* partial, int fast_exp, hipStream_t stream) {
   ZT_REQUIRE(L2 && s2 && Y && scal && ds2 && partial && H > 2 && W > 2);
   SmoothCoef sc;
   for (int k = 0; k < 12; ++k) {
     const int adx = k_off_dx[k] < 0 ? -k_off_dx[k] : k_off_dx[k];
     sc.coef[k] = 10.f / ((float)(H - k_off_dy[k]) * (float)(W - adx));      // same fp32 expression the kernel used to evaluate per pixel
   }
-  hipLaunchKernelGGL(loss_s2_kernel, dim3(zt_cdiv(W, LS_TX), zt_cdiv(H, LS_TY)), dim3(64, 4), 0, stream, L2, s2, Y, scal, H, W, ds2, partial,
-                     zt_cdiv(H, 4), sc);
+  const dim3 grid(zt_cdiv(W, LS_TX), zt_cdiv(H, LS_TY));
+  if (fast_exp) hipLaunchKernelGGL(loss_s2_kernel<true>, grid, dim3(64, 4), 0, stream, L2, s2, Y, scal, H, W, ds2, partial, zt_cdiv(H, 4), sc);
+  else hipLaunchKernelGGL(loss_s2_kernel<false>, grid, dim3(64, 4), 0, stream, L2, s2, Y, scal, H, W, ds2, partial, zt_cdiv(H, 4), sc);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

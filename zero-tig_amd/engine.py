@@ -317,7 +317,7 @@ class Engine:
         ds2 = self._new(1, 3, H, W)
         nb1 = ((W + 63) // 64) * ((H + 3) // 4)
         p1 = self._new(nb1, 4)
-        lib.call("zt_loss_s2_f32", v["L2"], v["s2"], Y, scal, H, W, ds2, p1, s)
+        lib.call("zt_loss_s2_f32", v["L2"], v["s2"], Y, scal, H, W, ds2, p1, self.dt, s)
         o.partial_reduce(p1, nb1, 4, 4, out=terms)
         # ---- half-resolution terms
         LM1, LM2 = o.box5_reflect(v["H3d1"]), o.box5_reflect(v["H3d2"])
@@ -421,6 +421,6 @@ def smooth_tv_values(ops, L2, s2):
     scal = torch.ones(8, dtype=torch.float32, device=L2.device)
     nb1 = ((W + 63) // 64) * ((H + 3) // 4)
     p1, ds2, out = eng._new(nb1, 4), eng._new(1, 3, H, W), eng._new(4)
-    ops.lib.call("zt_loss_s2_f32", L2c, s2c, Y, scal, H, W, ds2, p1, eng._stream())
+    ops.lib.call("zt_loss_s2_f32", L2c, s2c, Y, scal, H, W, ds2, p1, 0, eng._stream())
     ops.partial_reduce(p1, nb1, 4, 4, out=out)
     return out[2] / 5.0, out[3] / 1600.0
