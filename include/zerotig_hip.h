@@ -292,6 +292,12 @@ int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, 
  * slab[i] into grad_w[i] ([Cout][Cin][K][K]) and grad_b[i] (may be NULL), (+)= when accumulate.  All array arguments are host arrays. */
 int zt_conv2d_wgrad_partial_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout, int KH, int KW,
                                  float* slab, size_t slab_bytes, const void* relu_mask, int ldmask, int* nslab_out, zt_stream_t stream);
+/* Backward of Denoise_1/2's 1x1 output layer (model.py:27, 43) in one pass over its operands: dz[p][48] = (W^T dr[p]) * LeakyReLU'(a2[p])
+ * (what zt_conv2d_nhwc_bf16 with the transposed weights wT [48][8] and epi 1 computes) AND the layer's weight / bias gradient slabs
+ * ([48][16] + [16] floats each, *nslab_out of them appended at `slab`: feed to zt_wgrad_reduce_multi_f32 with Cin 48, Cout Cdr, K 1).
+ * dr: nhwc bf16 [HW][8] with Cdr = 3 or 6 valid channels; a2 / dz: nhwc bf16, channel strides lda / lddz >= 48. */
+int zt_thin1x1_bwd_bf16(const void* dr, int Cdr, const void* wT, const void* a2, int lda, void* dz, int lddz, int HW, float* slab,
+                        size_t slab_bytes, int* nslab_out, zt_stream_t stream);
 int zt_wgrad_reduce_multi_f32(int nseg, const void* const* slab, const int* nslab, const int* Cin, const int* Cout, const int* K,
                               void* const* grad_w, void* const* grad_b, int accumulate, zt_stream_t stream);
 /* all weight repacks of a step in one launch (up to 24 entries; host arrays; square kernels K x K; same layouts as the single form) */

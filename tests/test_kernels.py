@@ -331,6 +331,35 @@ def test_raft_ops_golden(backend, oracle, synth):
     assert torch.equal(look2.cpu().permute(0, 3, 1, 2), oracle.corr_lookup(pyr, coords))
 
 
+@pytest.mark.parametrize("Cdr,hw", [(3, (9, 41)), (6, (27, 101)), (6, (64, 96))], ids=["c3-9x41", "c6-27x101", "c6-64x96"])
+def test_thin1x1_bwd_fused(backend, Cdr, hw):
+    """Denoise_1/2 conv3 backward in one pass (zt_thin1x1_bwd_bf16): the data gradient must be bit-identical to the 1x1 thin
+    data-gradient kernel's, the weight / bias gradients must match autograd (and the separate weight-gradient kernel)."""
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    H, W = hw
+    g = torch.Generator().manual_seed(Cdr * 100 + H)
+    a2 = torch.randn(1, 48, H, W, generator=g).bfloat16().float()
+    dr = torch.randn(1, Cdr, H, W, generator=g).bfloat16().float()
+    w3 = torch.randn(Cdr, 48, 1, 1, generator=g) * 0.2
+    wT = ops.repack_weight_bf16(w3.to(dev), transpose_flip=True)
+    a2d, drd = _nhwc_bf16(a2, 48).to(dev), _nhwc_bf16(dr, 8).to(dev)
+    per = ops.wgrad_slab_floats(48, Cdr, 1)
+    slab = torch.full((600 * per,), float("nan"), device=dev)
+    dz, n = ops.thin1x1_bwd_bf16(drd, Cdr, wT, a2d, slab, 0)
+    ref_dz = ops.conv2d_bf16(CV(drd, 0, Cdr), wT, None, 48, 1, 1, (0, 0), None, aux=a2d, epi=1)
+    assert torch.equal(dz.cpu(), ref_dz.cpu()[..., :48])
+    gw, gb = torch.zeros(Cdr, 48, 1, 1, device=dev), torch.zeros(Cdr, device=dev)
+    ops.wgrad_reduce_multi([(slab, n, 48, Cdr, 1, gw, gb)], accumulate=False)
+    ref_w = torch.einsum("nohw,nihw->oi", dr, a2)
+    assert maxerr(gw.view(Cdr, 48), ref_w) < 2e-5 * float(ref_w.abs().max()) + 1e-4, maxerr(gw.view(Cdr, 48), ref_w)
+    assert maxerr(gb, dr.sum(dim=(0, 2, 3))) < 1e-4 * (H * W) ** 0.5
+    g2, b2 = torch.zeros_like(gw), torch.zeros_like(gb)
+    ops.conv2d_wgrad_bf16(CV(a2d, 0, 48), CV(drd, 0, Cdr), Cdr, 1, 1, g2, grad_b=b2)
+    assert maxerr(gw, g2) < 2e-5 * float(ref_w.abs().max()) + 1e-4
+
+
 @pytest.mark.parametrize("pair", [(324, 256, 1, 2, 128, 7), (256, 192, 3, 128, 64, 3), (96, 64, 3, 40, 32, 3)], ids=["1x1+7x7", "3x3+3x3", "fallback"])
 def test_conv_pair_equals_two_launches(backend, pair):
     """zt_conv2d_pair_nhwc_bf16 (RAFT motion encoder: convc1 || convf1, convc2 || convf2 in one launch each) against the same two

@@ -1277,6 +1277,105 @@ __global__ void __launch_bounds__(256) conv1x1_thin_bf16_kernel(ConvArgsH a, int
   }
 }
 
+// ---- Backward of Denoise_1/2's 1x1 output layer (model.py:27, 43: conv3, 48 -> 3 / 6) in ONE pass over its two operands.
+// The data gradient dz2 = (W3^T dr) * LeakyReLU'(a2) and the weight / bias gradients dW3[co][ci] = sum_p dr[p][co] a2[p][ci],
+// db3[co] = sum_p dr[p][co] read the same a2 (48 ch) and dr (8 ch) pixels: two launches (conv1x1_thin 43 us + wgrad<1,1,3,1,4> 34 us
+// per call, six calls per step) each streamed a2 once; here it is streamed once for both.  Same thread layout as conv1x1_thin
+// (thread = 4 pixels x one 8-channel octet of a2 / dz2, 16-byte accesses), as a grid-stride loop so that the 6 x 8 products per
+// pixel accumulate in registers; a workgroup = 42 pixel groups x 6 octets (252 of 256 threads); at the end the 42 partial sets of
+// an octet are summed in a FIXED order through LDS (bit-reproducible: no atomics) into one slab of the layout the batched slab
+// reduction expects ([ci 48][co 16] + [co 16]).  dz2 is bit-identical to conv1x1_thin_bf16_kernel<true>'s.
+struct ThinBwdArgs {
+  const zt_bf16* dr;       // [HW][8]   gradient of the 1x1 output (Cdr = 3 or 6 valid channels)
+  const zt_bf16* wT;       // [48][8]   data-gradient operator: row = a2 channel, column = output channel (zero beyond Cdr)
+  const zt_bf16* a2;       // [HW][lda] the layer's input activation (LeakyReLU output)
+  zt_bf16* dz;             // [HW][lddz] data gradient w.r.t. the pre-activation of a2
+  float* slab;             // [grid][48 * 16 + 16]
+  int HW, npg, lda, lddz, Cdr;
+};
+
+__global__ void __launch_bounds__(256) thin1x1_bwd_bf16_kernel(ThinBwdArgs a) {
+  __shared__ float red[252 * 49];                                // 48 products + pad: per-thread partial sets, then the bias sets
+  const int tid = threadIdx.x;
+  const int o = tid % 6, gl = tid / 6;                           // octet of a2 / dz2, pixel group inside the workgroup (0..41; 42: idle)
+  const bool active = tid < 252;
+  float w[8][8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) zt_ld8(a.wT + (size_t)(o * 8 + c) * 8, w[c]);
+  float acc[6][8], bsum[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    bsum[k] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
+  }
+  for (int pg = blockIdx.x * 42 + gl; active && pg < a.npg; pg += gridDim.x * 42) {
+    float x[4][8], u[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = min(pg + j * a.npg, a.HW - 1);
+      zt_ld8(a.dr + (size_t)p * 8, x[j]);
+      zt_ld8(a.a2 + (size_t)p * a.lda + o * 8, u[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)                                 // the buffer's padding lanes are not trusted (NaN * 0)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[j][k] = k < a.Cdr ? x[j][k] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = pg + j * a.npg;
+      float r[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum = fmaf(w[c][k], x[j][k], sum);
+        r[c] = sum * (u[j][c] > 0.f ? 1.f : 0.2f);
+      }
+      if (p < a.HW) {
+        zt_st8(a.dz + (size_t)p * a.lddz + o * 8, r);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          bsum[k] += x[j][k];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[k][c] = fmaf(x[j][k], u[j][c], acc[k][c]);
+        }
+      }
+    }
+  }
+  // deterministic workgroup reduction: every thread publishes its 48 partial products, then (ci, co) is summed over the 42 pixel
+  // groups of its octet in index order; the bias sums (identical in the 6 octet threads of a pixel group) go through the same buffer
+  float* out = a.slab + (size_t)blockIdx.x * (48 * 16 + 16);
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) red[tid * 49 + k * 8 + c] = acc[k][c];
+  }
+  __syncthreads();
+  for (int e = tid; e < 48 * 16; e += 256) {
+    const int ci = e >> 4, co = e & 15;
+    float sum = 0.f;
+    if (co < 6) {
+      const int oo = ci >> 3, c = ci & 7;
+      for (int g = 0; g < 42; ++g) sum += red[(g * 6 + oo) * 49 + co * 8 + c];
+    }
+    out[e] = sum;
+  }
+  __syncthreads();
+  if (active && o == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[gl * 8 + k] = bsum[k];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float sum = 0.f;
+    if (tid < 6)
+      for (int g = 0; g < 42; ++g) sum += red[g * 8 + tid];
+    out[48 * 16 + tid] = sum;
+  }
+}
+
 // ---- 1x1 convolution with a thin fp32 planar output (Cout <= 8: the 48 -> 3 / 48 -> 6 output layers of Denoise_1/2).  Streaming:
 // thread = one pixel, reads its Cin/8 16-byte chunks (a wave reads one contiguous span), weights are wave-uniform (scalar
 // loads), each output plane is written coalesced.
@@ -2663,6 +2762,24 @@ extern "C" int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(zt_cdiv(total, 32)), dim3(256), 0, stream, (const float*)slab, nblk, KH * KW,
                      CT * 16, NT * 16, grad_w, Cout, Cin, accumulate, grad_b);
   ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_thin1x1_bwd_bf16(const void* dr, int Cdr, const void* wT, const void* a2, int lda, void* dz, int lddz, int HW, float* slab,
+                                   size_t slab_bytes, int* nslab_out, hipStream_t stream) {
+  ZT_REQUIRE(dr && wT && a2 && dz && slab && nslab_out && HW > 0 && (Cdr == 3 || Cdr == 6) && lda % 8 == 0 && lddz % 8 == 0 && lda >= 48 && lddz >= 48);
+  ZT_REQUIRE(((uintptr_t)dr & 15) == 0 && ((uintptr_t)wT & 15) == 0 && ((uintptr_t)a2 & 15) == 0 && ((uintptr_t)dz & 15) == 0);
+  ThinBwdArgs a;
+  a.dr = (const zt_bf16*)dr; a.wT = (const zt_bf16*)wT; a.a2 = (const zt_bf16*)a2; a.dz = (zt_bf16*)dz; a.slab = slab;
+  a.HW = HW; a.npg = zt_cdiv(HW, 4); a.lda = lda; a.lddz = lddz; a.Cdr = Cdr;
+  const size_t per = (48 * 16 + 16) * sizeof(float);
+  int nblk = zt_cdiv(a.npg, 42);
+  if (nblk > 512) nblk = 512;
+  if ((size_t)nblk * per > slab_bytes) nblk = (int)(slab_bytes / per);
+  ZT_REQUIRE(nblk >= 1);
+  hipLaunchKernelGGL(thin1x1_bwd_bf16_kernel, dim3(nblk), dim3(256), 0, stream, a);
+  ZT_LAUNCH_CHECK();
+  *nslab_out = nblk;
   return ZT_OK;
 }
 

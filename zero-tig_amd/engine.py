@@ -13,6 +13,10 @@ from .ops import CV
 TERM_NAMES = ["enh_s2", "enh_norm", "smooth", "tv", "res1_a", "res1_b", "res1_c", "res1_d", "res2_a", "res2_b", "res2_c",
               "res2_d", "color", "ill", "inter_a", "inter_b", "var"]
 
+import os
+
+_FUSED_THIN_BWD = os.environ.get("ZT_FUSED_THIN_BWD", "1") == "1"      # A/B knob: 0 = separate 1x1 data-gradient and weight-gradient launches
+
 D1 = "denoise_1"
 D2 = "denoise_2"
 
@@ -115,6 +119,24 @@ class Engine:
             return
         ent["n"] += o.wgrad_partial_bf16(xv, dz, cout, k, slab, ent["n"] * per, relu_mask=relu_mask)
 
+    def _thin_bwd(self, a2, dr, cout, pre):
+        """Denoise conv3 backward (bf16 mode): appends the layer's weight-gradient slabs like `_wgrad` and returns dz2."""
+        o = self.ops
+        per = o.wgrad_slab_floats(48, cout, 1)
+        ent = self._wg.get(pre)
+        if ent is None:
+            ent = self._wg[pre] = {"n": 0, "Cin": 48, "Cout": cout, "K": 1, "per": per}
+        slab = self._wg_slab.get(pre)
+        need = (ent["n"] + 512) * per
+        if slab is None or slab.numel() < need:
+            new = torch.empty(max(need, 3 * 512 * per if slab is None else need), dtype=torch.float32, device=self.dev)
+            if slab is not None and ent["n"]:
+                new[:ent["n"] * per].copy_(slab[:ent["n"] * per])
+            slab = self._wg_slab[pre] = new
+        dz2, n = o.thin1x1_bwd_bf16(dr, cout, self.wd[pre + "/T"], a2, slab, ent["n"] * per)
+        ent["n"] += n
+        return dz2
+
     def _wgrad_flush(self):
         if self._wg_forked:
             torch.cuda.current_stream(self.dev).wait_stream(self._wg_stream)
@@ -157,8 +179,12 @@ class Engine:
         [1,cin,H,W] gradient of the packed input when requested."""
         u, a1, a2, cin = self.sv[key]
         drv = CV(dr, 0, cout)
-        self._wgrad(a2, drv, cout, 1, pre + ".conv3")
-        dz2 = self._conv(drv, pre + ".conv3/T", None, 48, 1, None, aux=a2, epi=1)
+        if self.dt and _FUSED_THIN_BWD and tuple(self.wd[pre + ".conv3/T"].shape[-2:]) == (48, 8):
+            # conv3 (1x1, 48 -> 3 / 6): data gradient and weight / bias gradient slabs from ONE pass over a2 and dr
+            dz2 = self._thin_bwd(a2, dr, cout, pre + ".conv3")
+        else:
+            self._wgrad(a2, drv, cout, 1, pre + ".conv3")
+            dz2 = self._conv(drv, pre + ".conv3/T", None, 48, 1, None, aux=a2, epi=1)
         self._wgrad(a1, dz2, 48, 3, pre + ".conv2")
         dz1 = self._conv(dz2, pre + ".conv2/T", None, 48, 3, None, aux=a1, epi=1)
         self._wgrad(CV(u, 0, cin), dz1, 48, 3, pre + ".conv1")

@@ -550,6 +550,19 @@ class Ops:
         self._ev_end(tok)
         return n.value
 
+    def thin1x1_bwd_bf16(self, dr, Cdr, wT, a2, slab, slab_off):
+        """Denoise_1/2 conv3 backward in one pass (zt_thin1x1_bwd_bf16): dr [1,H,W,8] bf16 gradient of the 1x1 output, wT the
+        transposed-weight tensor of the data gradient ([1][48][8] bf16), a2 [1,H,W,>=48] bf16.  -> (dz2 [1,H,W,48] bf16, slabs written)."""
+        import ctypes
+        dr, a2 = _cv(dr), _cv(a2)
+        assert dr.t.dtype == a2.t.dtype == wT.dtype == torch.bfloat16 and dr.ld == 8 and dr.N == 1 and (dr.H, dr.W) == (a2.H, a2.W)
+        assert tuple(wT.shape[-2:]) == (48, 8) and a2.C >= 48
+        dz = torch.empty((1, a2.H, a2.W, 48), dtype=torch.bfloat16, device=a2.t.device)
+        n = ctypes.c_int(0)
+        self.lib.call("zt_thin1x1_bwd_bf16", dr.ptr, Cdr, wT, a2.ptr, a2.ld, dz, 48, a2.H * a2.W, slab.data_ptr() + 4 * slab_off,
+                      (slab.numel() - slab_off) * 4, ctypes.byref(n), self._s(a2.t))
+        return dz, n.value
+
     @staticmethod
     def wgrad_slab_floats(Cin, Cout, K):
         c16 = lambda c: (c + 15) // 16 * 16
