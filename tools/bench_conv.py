@@ -33,6 +33,11 @@ def run(cin, cout, k, variant, epi=0, iters=10):
 
 AB_MODE = os.environ.get("ZT_BENCH_AB")
 names = {3: "register-stationary", 33: "rs no-mfma", 34: "rs no-store", 36: "rs no-halo", 38: "rs mfma only", 39: "rs barriers only", 1: "ws full", 2: "tiled"}
+ONLY = os.environ.get("ZT_BENCH_ONLY")
+if ONLY:          # one variant of one layer, for counter collection: ZT_BENCH_ONLY="64,64,3[,epi]"
+    t = [int(v) for v in ONLY.split(",")]
+    print("c%d->%d variant %d epi %d: %7.1f us" % (t[0], t[1], t[2], t[3] if len(t) > 3 else 0, run(t[0], t[1], 3, t[2], epi=t[3] if len(t) > 3 else 0, iters=30)), flush=True)
+    sys.exit(0)
 ABL = os.environ.get("ZT_BENCH_ABL")
 if ABL:           # phase ablations of the register-stationary kernel on one layer: ZT_BENCH_ABL="9,64"
     cin, cout = (int(t) for t in ABL.split(","))

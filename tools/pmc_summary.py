@@ -9,7 +9,8 @@ import json
 import re
 import sys
 
-WIDE = ("conv_rs_bf16", "conv_ws_bf16", "conv_mfma_bf16", "wgrad_mfma_bf16", "bn_bwd", "norm_apply", "chan_stats", "relu_mask")
+WIDE = ("conv_rs_bf16", "conv_ws_bf16", "conv_mfma_bf16", "wgrad_mfma_bf16", "wgrad64_dma_bf16", "corr_pyramid_bf16", "thin1x1_bwd_bf16", "conv1x1_thin",
+        "stats_bf16x8", "bn_bwd", "norm_apply", "chan_stats", "relu_mask")
 
 
 def short(name):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the round's judged artifacts (arg 1 = tag): default bench line (with the CPU baseline), rocprofv3 kernel stats of the
 # bench, FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, --kernel-trace only), and the other configurations' bench lines.
-tag=${1:-r02}
+tag=${1:-r03}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R

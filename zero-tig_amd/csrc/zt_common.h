@@ -195,6 +195,17 @@ __device__ __forceinline__ void zt_wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt(0x0F70 | N);
 }
 
+// max(a, b) as ONE v_max_f32: fmaxf() under -fno-fast-math first canonicalises operands that may be signalling NaNs (an extra
+// `v_max_f32 x, x, x` for every MFMA output).  Inputs here are finite.  The host-side test emulator pre-defines it as fmaxf.
+#ifndef ZT_VMAX
+__device__ __forceinline__ float zt_vmax_(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+#define ZT_VMAX(a, b) zt_vmax_((a), (b))
+#endif
+
 // make a value opaque to the optimiser (keeps per-iteration address arithmetic from being hoisted out of a persistent loop and
 // spilled).  The host-side test emulator pre-defines it as a no-op.
 #ifndef ZT_OPAQUE

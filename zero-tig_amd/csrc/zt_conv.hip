@@ -1842,13 +1842,12 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = acc[r][m][q][j];
-          if (a.alpha != 1.f) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= a.alpha;
-          }
+          // alpha == 1 on this path (rs_ok): hipcc had if-converted `if (alpha != 1) v *= alpha` into 2 packed multiplies + 4 selects
+          // per 4 values, executed always; and fmaxf() on MFMA outputs costs a canonicalising v_max per operand -- ZT_VMAX is the bare
+          // instruction.  The epilogue is the largest share of this VALU-issue co-limited kernel's 2.7 VALU per MFMA (section 5).
           if (a.act) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], slope * v[j]);
+            for (int j = 0; j < 4; ++j) v[j] = ZT_VMAX(v[j], slope * v[j]);
           }
           if constexpr (AUXD) {                                 // fused epilogue on the fp32 values: one rounding
             const uint2 u = au[AUXD ? r : 0][AUXD ? m : 0][AUXD ? q : 0];
@@ -2593,7 +2592,7 @@ static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, 
     return ZT_OK;
   }
   // register-stationary kernel: 3x3, bf16 nhwc output, 48 or 64 couts, input channels <= 16, 33..48 (Cout 48) or 49..64 (Cout 64)
-  const bool rs_ok = ws_ok && KH == 3 && out_mode == 0 && act <= 2 && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
+  const bool rs_ok = ws_ok && KH == 3 && out_mode == 0 && act <= 2 && alpha == 1.f && ldy % 8 == 0 && ((uintptr_t)y & 15) == 0 &&
                      (!aux || (ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0)) && ldx >= 8 &&
                      ((Cout == 64 && (Cin <= 16 || Cin == 56 || Cin == 64)) || (Cout == 48 && (Cin <= 16 || Cin == 40 || Cin == 48)));
   ZT_REQUIRE(variant != 3 || rs_ok);

@@ -6,6 +6,7 @@
 // (fma source index, fma row interpolation, ix = fma(g+1, W/2, -0.5)); this file is compiled with
 // -ffp-contract=off so only the explicit fmaf() calls fuse.
 #include "zt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -240,17 +241,21 @@ extern "C" int zt_warp2_f32(const float* flow, int Hf, int Wf, const float* imgA
   float xden = (float)(((double)W - 1.0) / 2.0), yden = (float)(((double)H - 1.0) / 2.0);
   float halfW = (float)W / 2.f, halfH = (float)H / 2.f;
   if (C == 3) {       // the path's only use (3-channel frames): tiled kernel, flow window in LDS
-    constexpr int PPT = 2;
+    static const int ppt = getenv("ZT_WARP_PPT") ? atoi(getenv("ZT_WARP_PPT")) : 2;      // tuning hook: pixels (rows) per thread, 2 or 4
+    const int PPT = ppt == 4 ? 4 : 2;
     // upper bound of the flow window of a 64 x (4 PPT) tile: ceil(extent * scale) + 2 (the i0..i1 span of both ends)
     const int fwin_w = (int)(64.0 * Wf / W) + 3, fwin_h = (int)(4.0 * PPT * Hf / H) + 3;
     if (fwin_w <= WARP_FWW && fwin_h <= 4 * PPT + 4) {
       dim3 grid(zt_cdiv(W, 64), zt_cdiv(H, 4 * PPT)), block(64, 4);
-      if (imgB)
-        hipLaunchKernelGGL((warp2_tiled_kernel<PPT, true>), grid, block, 0, stream, flow, Hf, Wf, imgA, imgB, outA, outB, taps, H, W,
-                           h_scale, w_scale, sc_h, sc_w, xden, yden, halfW, halfH);
-      else
-        hipLaunchKernelGGL((warp2_tiled_kernel<PPT, false>), grid, block, 0, stream, flow, Hf, Wf, imgA, imgB, outA, outB, taps, H, W,
-                           h_scale, w_scale, sc_h, sc_w, xden, yden, halfW, halfH);
+#define ZT_WARP_LAUNCH(P, T)                                                                                                          \
+  hipLaunchKernelGGL((warp2_tiled_kernel<P, T>), grid, block, 0, stream, flow, Hf, Wf, imgA, imgB, outA, outB, taps, H, W, h_scale, w_scale, \
+                     sc_h, sc_w, xden, yden, halfW, halfH)
+      if (PPT == 4) {
+        if (imgB) ZT_WARP_LAUNCH(4, true); else ZT_WARP_LAUNCH(4, false);
+      } else {
+        if (imgB) ZT_WARP_LAUNCH(2, true); else ZT_WARP_LAUNCH(2, false);
+      }
+#undef ZT_WARP_LAUNCH
       ZT_LAUNCH_CHECK();
       return ZT_OK;
     }
