@@ -630,28 +630,29 @@ def test_conv_wgrad_bf16(backend, case):
             assert torch.equal(g1, g2) and torch.equal(b1, b2) and float(g1.abs().max()) > 0
 
 
+@pytest.mark.parametrize("ch", [64, 48])
 @pytest.mark.parametrize("nblk", [3, 8, 256])
-def test_conv_wgrad64_dma_double_buffer(backend, nblk, monkeypatch):
-    """The LDS-DMA form of the 64 -> 64 weight gradient with FEWER workgroups than tiles (ZT_WGRAD_BLOCKS): every workgroup walks
+def test_conv_wgrad64_dma_double_buffer(backend, nblk, ch, monkeypatch):
+    """The LDS-DMA form of the 64 -> 64 / 48 -> 48 weight gradient with FEWER workgroups than tiles (ZT_WGRAD_BLOCKS): every workgroup walks
     several tiles through both LDS buffers (nblk 3: plain tile order; 8: the XCD-banded order), ragged right / bottom tiles, against
     autograd and against the register-staged kernel (ZT_WGRAD_DMA=0) on the same operands."""
     import torch.nn.functional as F
     from importlib import import_module
     CV = import_module("zero-tig_amd.ops").CV
     ops, dev, _ = backend
-    g = torch.Generator().manual_seed(nblk)
+    g = torch.Generator().manual_seed(nblk + ch)
     for (H, W) in ((43, 70), (16, 129)):
-        x = torch.randn(1, 64, H, W, generator=g).bfloat16().float()
-        dz = torch.randn(1, 64, H, W, generator=g).bfloat16().float()
-        w = torch.zeros(64, 64, 3, 3, requires_grad=True)
+        x = torch.randn(1, ch, H, W, generator=g).bfloat16().float()
+        dz = torch.randn(1, ch, H, W, generator=g).bfloat16().float()
+        w = torch.zeros(ch, ch, 3, 3, requires_grad=True)
         (F.conv2d(x, w, None, padding=1) * dz).sum().backward()
-        xd, dzd = CV(_nhwc_bf16(x, 72).to(dev), 0, 64), CV(_nhwc_bf16(dz, 64).to(dev), 0, 64)
+        xd, dzd = CV(_nhwc_bf16(x, ch + 8).to(dev), 0, ch), CV(_nhwc_bf16(dz, ch).to(dev), 0, ch)
         res = {}
         for dma in ("1", "0"):
             monkeypatch.setenv("ZT_WGRAD_DMA", dma)
             monkeypatch.setenv("ZT_WGRAD_BLOCKS", str(nblk))
-            gw, gb = torch.full((64, 64, 3, 3), 3.0, device=dev), torch.full((64,), 3.0, device=dev)
-            ops.conv2d_wgrad_bf16(xd, dzd, 64, 3, 3, gw, grad_b=gb)
+            gw, gb = torch.full((ch, ch, 3, 3), 3.0, device=dev), torch.full((ch,), 3.0, device=dev)
+            ops.conv2d_wgrad_bf16(xd, dzd, ch, 3, 3, gw, grad_b=gb)
             res[dma] = (gw.cpu(), gb.cpu())
             assert maxerr(gw, w.grad) < 2e-3 * float(w.grad.abs().max()), (dma, maxerr(gw, w.grad))
             assert maxerr(gb, dz.sum(dim=(0, 2, 3))) < 1e-3 * (H * W) ** 0.5

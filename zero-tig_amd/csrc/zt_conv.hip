@@ -2180,14 +2180,23 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && CT == 4 && NT == 4) ? 2 :
 //    over 8 waves) instead of 32 two-byte LDS reads + adds per thread and tile;
 //  * XCD-aware banded tile order as in conv_rs, so a tile's halo rows / columns are in its XCD's L2.
 // Requires Cin == Cout == 64 and channel strides >= 64 (multiples of 8).
-constexpr int WG64_IR = 10, WG64_IC = 34, WG64_XE = WG64_IR * WG64_IC * 64, WG64_ZE = 8 * HTW * 64;
+// CH = 48 (Denoise_1/2 conv2, six launches per step; round 3): the same kernel on 96-byte pixel rows.  A lane-linear DMA image cannot
+// be padded and 6 chunks per pixel cannot be XOR-swizzled, so the transposing reads keep a 2-way conflict ({c..c+3} against
+// {c+8..c+11}: every pitch from 96 to 208 bytes gives 2-way, brute force) -- the loop is VALU / MFMA bound, not LDS bound.  27 pairs
+// over 8 waves: 4 slots per wave, the bias sums in wave 3's spare one.
+constexpr int WG64_IR = 10, WG64_IC = 34;
 
-__device__ __forceinline__ int wg64_swz(int col) { return ((col >> 1) & 1) | (((col >> 3) & 1) << 1); }
+template <int CH>
+__device__ __forceinline__ int wg64_swz(int col) { return CH == 64 ? (((col >> 1) & 1) | (((col >> 3) & 1) << 1)) : 0; }
 
+template <int CH>
 __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) {
-  constexpr int NW = 8, NTHR = 512, HTH = 8, IR = WG64_IR, IC = WG64_IC, CT = 4, NT = 4;
-  constexpr int NPAIR = 36, PPW = 5;
-  constexpr int NGX = (IR * IC * 8 + NTHR - 1) / NTHR, NGZ = HTH * HTW * 8 / NTHR;          // DMA wave-instructions per wave and tile: 6 + 4
+  static_assert(CH == 64 || CH == 48, "pixel rows of 128 or 96 bytes");
+  constexpr int NW = 8, NTHR = 512, HTH = 8, IR = WG64_IR, IC = WG64_IC, CT = CH / 16, NT = CH / 16, CK = CH / 8;
+  constexpr int NPAIR = 9 * CT, PPW = (NPAIR + NW - 1) / NW;
+  constexpr int WG64_XE = IR * IC * CH, WG64_ZE = HTH * HTW * CH;
+  constexpr int NGX = (IR * IC * CK + NTHR - 1) / NTHR, NGZ = (HTH * HTW * CK + NTHR - 1) / NTHR;      // DMA wave-instructions per wave and tile
+  static_assert(HTH * HTW * CK % 64 == 0, "dz image = whole wave-instructions");
   __shared__ __attribute__((aligned(16))) zt_bf16 smem[2 * (WG64_XE + WG64_ZE)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2213,14 +2222,14 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
 #pragma unroll
   for (int i = 0; i < NGX; ++i) {
     const int e = (i * NW + wave) * 64 + lane;
-    const int p = e >> 3, row = p / IC, col = p - row * IC;
-    xoff[i] = (row * a.W + col) * a.ldx + (((e & 7) ^ (wg64_swz(col) << 1)) * 8);
+    const int p = e / CK, row = p / IC, col = p - row * IC;
+    xoff[i] = (row * a.W + col) * a.ldx + (((e - p * CK) ^ (wg64_swz<CH>(col) << 1)) * 8);
   }
 #pragma unroll
   for (int i = 0; i < NGZ; ++i) {
     const int e = (i * NW + wave) * 64 + lane;
-    const int p = e >> 3, row = p / HTW, col = p - row * HTW;
-    zoff[i] = (row * a.W + col) * a.lddz + (((e & 7) ^ (wg64_swz(col) << 1)) * 8);
+    const int p = e / CK, row = p / HTW, col = p - row * HTW;
+    zoff[i] = (row * a.W + col) * a.lddz + (((e - p * CK) ^ (wg64_swz<CH>(col) << 1)) * 8);
   }
   auto dma_tile = [&](int idx, int buf) {
     int ty, tx;
@@ -2233,9 +2242,10 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
       const zt_bf16* zo = a.dz + (unsigned)((oy0 * a.W + ox0) * a.lddz);
 #pragma unroll
       for (int i = 0; i < NGX; ++i)
-        if ((i * NW + NW) * 64 <= IR * IC * 8 || (i * NW + wave) * 64 + lane < IR * IC * 8) ZT_GLDS16_HIDDEN(xo + xoff[i], xb + (i * NW + wave) * 512);
+        if ((i * NW + NW) * 64 <= IR * IC * CK || (i * NW + wave) * 64 + lane < IR * IC * CK) ZT_GLDS16_HIDDEN(xo + xoff[i], xb + (i * NW + wave) * 512);
 #pragma unroll
-      for (int i = 0; i < NGZ; ++i) ZT_GLDS16_HIDDEN(zo + zoff[i], zb + (i * NW + wave) * 512);
+      for (int i = 0; i < NGZ; ++i)
+        if ((i * NW + NW) * 64 <= HTH * HTW * CK || (i * NW + wave) * 64 < HTH * HTW * CK) ZT_GLDS16_HIDDEN(zo + zoff[i], zb + (i * NW + wave) * 512);
       return;
     }
     int ln = lane;
@@ -2243,24 +2253,24 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
 #pragma unroll
     for (int i = 0; i < NGX; ++i) {
       const int e = (i * NW + wave) * 64 + ln;
-      const int p = e >> 3, row = p / IC, col = p - row * IC;
-      const int cj = (e & 7) ^ (wg64_swz(col) << 1);
+      const int p = e / CK, row = p / IC, col = p - row * IC;
+      const int cj = (e - p * CK) ^ (wg64_swz<CH>(col) << 1);
       const int gy = oy0 - 1 + row, gx = ox0 - 1 + col;
       const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       const int gyc = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
       const void* src = in ? (const void*)(a.x + (unsigned)((gyc * a.W + gxc) * a.ldx + cj * 8)) : (const void*)&zt_zero_chunk;
-      if ((i * NW + NW) * 64 <= IR * IC * 8 || e < IR * IC * 8) ZT_GLDS16_HIDDEN(src, xb + (i * NW + wave) * 512);
+      if ((i * NW + NW) * 64 <= IR * IC * CK || e < IR * IC * CK) ZT_GLDS16_HIDDEN(src, xb + (i * NW + wave) * 512);
     }
 #pragma unroll
     for (int i = 0; i < NGZ; ++i) {
       const int e = (i * NW + wave) * 64 + ln;
-      const int p = e >> 3, row = p / HTW, col = p - row * HTW;
-      const int cj = (e & 7) ^ (wg64_swz(col) << 1);
+      const int p = e / CK, row = p / HTW, col = p - row * HTW;
+      const int cj = (e - p * CK) ^ (wg64_swz<CH>(col) << 1);
       const int gy = oy0 + row, gx = ox0 + col;
       const bool in = gy < a.H && gx < a.W;
       const int gyc = gy >= a.H ? a.H - 1 : gy, gxc = gx >= a.W ? a.W - 1 : gx;
       const void* src = in ? (const void*)(a.dz + (unsigned)((gyc * a.W + gxc) * a.lddz + cj * 8)) : (const void*)&zt_zero_chunk;
-      ZT_GLDS16_HIDDEN(src, zb + (i * NW + wave) * 512);
+      if ((i * NW + NW) * 64 <= HTH * HTW * CK || (i * NW + wave) * 64 < HTH * HTW * CK) ZT_GLDS16_HIDDEN(src, zb + (i * NW + wave) * 512);
     }
   };
 
@@ -2280,19 +2290,19 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
     const int tap = pr / CT, cit = pr - tap * CT;
     const int ky = tap / 3, kx = tap - ky * 3;
     const int c0 = kx + g8 + trq, c1 = c0 + 4;
-    alo[pi] = (ky * IC + c0) * 64 + ((cit ^ wg64_swz(c0)) * 16) + trp;
-    ahi[pi] = (ky * IC + c1) * 64 + ((cit ^ wg64_swz(c1)) * 16) + trp;
+    alo[pi] = (ky * IC + c0) * CH + ((cit ^ wg64_swz<CH>(c0)) * 16) + trp;
+    ahi[pi] = (ky * IC + c1) * CH + ((cit ^ wg64_swz<CH>(c1)) * 16) + trp;
   }
   int blo[NT], bhi[NT];
   {
     const int c0 = g8 + trq, c1 = c0 + 4;
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
-      blo[q] = WG64_XE + c0 * 64 + ((q ^ wg64_swz(c0)) * 16) + trp;
-      bhi[q] = WG64_XE + c1 * 64 + ((q ^ wg64_swz(c1)) * 16) + trp;
+      blo[q] = WG64_XE + c0 * CH + ((q ^ wg64_swz<CH>(c0)) * 16) + trp;
+      bhi[q] = WG64_XE + c1 * CH + ((q ^ wg64_swz<CH>(c1)) * 16) + trp;
     }
   }
-  const bool ones_slot = wave == 4;                              // uniform: pair slot PPW - 1 of wave 4 = bias column sums
+  const bool ones_slot = wave == NPAIR % NW;                     // uniform: the first wave whose last pair slot is spare = bias column sums
   const zt_s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};     // bf16 1.0
 
   const int n_my = pb < a.ntiles ? (a.ntiles - 1 - pb) / G + 1 : 0;
@@ -2324,16 +2334,16 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
     auto load_a = [&](auto bc, auto rc, auto pc) {
       constexpr int bi = decltype(bc)::value, pi = decltype(pc)::value;
       constexpr int row = decltype(rc)::value < HTH ? decltype(rc)::value : HTH - 1;
-      fal[bi] = zt_lds_read_tr16(pal[pi] + row * IC * 64);
-      fah[bi] = zt_lds_read_tr16(pah[pi] + row * IC * 64);
+      fal[bi] = zt_lds_read_tr16(pal[pi] + row * IC * CH);
+      fah[bi] = zt_lds_read_tr16(pah[pi] + row * IC * CH);
     };
     auto load_b = [&](auto bc, auto rc) {
       constexpr int bi = decltype(bc)::value;
       constexpr int row = decltype(rc)::value < HTH ? decltype(rc)::value : HTH - 1;
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
-        const zt_s16x4 lo = zt_lds_read_tr16(pbl[q] + row * HTW * 64);
-        const zt_s16x4 hi = zt_lds_read_tr16(pbh[q] + row * HTW * 64);
+        const zt_s16x4 lo = zt_lds_read_tr16(pbl[q] + row * HTW * CH);
+        const zt_s16x4 hi = zt_lds_read_tr16(pbh[q] + row * HTW * CH);
         bv[bi][q] = (zt_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     };
@@ -2358,8 +2368,8 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
       __builtin_amdgcn_sched_barrier(0);
     });
   }
-  // slab of this workgroup: [tap][ci 64][co 64] + [co 64] (same layout as wgrad_mfma_bf16_kernel)
-  float* out = a.slab + (size_t)blockIdx.x * (9 * 64 * 64 + 64);
+  // slab of this workgroup: [tap][ci CH][co CH] + [co CH] (same layout as wgrad_mfma_bf16_kernel)
+  float* out = a.slab + (size_t)blockIdx.x * (9 * CH * CH + CH);
   const int l4 = lane >> 4;
 #pragma unroll
   for (int pi = 0; pi < PPW; ++pi) {
@@ -2369,13 +2379,19 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
 #pragma unroll
       for (int q = 0; q < NT; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[((size_t)tap * 64 + cit * 16 + l4 * 4 + j) * 64 + q * 16 + l15] = acc[pi][q][j];
+        for (int j = 0; j < 4; ++j) out[((size_t)tap * CH + cit * 16 + l4 * 4 + j) * CH + q * 16 + l15] = acc[pi][q][j];
     }
   }
   if (ones_slot && l4 == 0) {          // every row of the ones product holds the column sums: row 0 (lanes 0..15, register 0)
 #pragma unroll
-    for (int q = 0; q < NT; ++q) out[9 * 64 * 64 + q * 16 + l15] = acc[PPW - 1][q][0];
+    for (int q = 0; q < NT; ++q) out[9 * CH * CH + q * 16 + l15] = acc[PPW - 1][q][0];
   }
+}
+
+// the 48 -> 48 3x3 layers take the DMA form too (ZT_WGRAD_DMA=0: the register-staged 4-wave kernel)
+static bool wgrad48_dma(int K, int Cin, int Cout, int ldx, int lddz) {
+  const int dma = getenv("ZT_WGRAD_DMA") ? atoi(getenv("ZT_WGRAD_DMA")) : 1;
+  return dma && K == 3 && Cin == 48 && Cout == 48 && ldx >= 48 && lddz >= 48 && ldx % 8 == 0 && lddz % 8 == 0;
 }
 
 template <int KH, int KW>
@@ -2391,7 +2407,13 @@ int launch_wgrad_h(const WgradArgsH& a, int CT, int NT, int nblk, hipStream_t st
     ZT_WG(1, 4, 4);
   }
   if (a.mask) return ZT_EINVAL;                                  // the folded ReLU mask exists for the thin-input 64-cout layer only
-  if (CT == 3 && NT == 3) { ZT_WG(3, 3, 4); }
+  if (CT == 3 && NT == 3) {
+    if (wgrad48_dma(KH, a.Cin, a.Cout, a.ldx, a.lddz)) {          // 8-row tiles, one workgroup per CU (ntiles / nblk sized for it by the caller)
+      hipLaunchKernelGGL(wgrad64_dma_bf16_kernel<48>, grid, dim3(512), 0, stream, a);
+      return 0;
+    }
+    ZT_WG(3, 3, 4);
+  }
   if (CT == 3 && NT == 1) { ZT_WG(3, 1, 4); }
   if (CT == 4 && NT == 4) {
     static const int nw4 = getenv("ZT_WGRAD_NW4") ? atoi(getenv("ZT_WGRAD_NW4")) : 0;      // tuning hook: 4-wave / 4-row form
@@ -2399,7 +2421,7 @@ int launch_wgrad_h(const WgradArgsH& a, int CT, int NT, int nblk, hipStream_t st
     const int dma = getenv("ZT_WGRAD_DMA") ? atoi(getenv("ZT_WGRAD_DMA")) : 1;             // 0: the register-staged form (A/B: tests, tools/bench_wgrad.py)
     if (dma && KH == 3 && KW == 3 && a.Cin == 64 && a.Cout == 64 && a.ldx >= 64 && a.lddz >= 64 && a.ldx % 8 == 0 && a.lddz % 8 == 0 &&
         a.ntiles % a.tilesX == 0) {
-      hipLaunchKernelGGL(wgrad64_dma_bf16_kernel, grid, dim3(512), 0, stream, a);
+      hipLaunchKernelGGL(wgrad64_dma_bf16_kernel<64>, grid, dim3(512), 0, stream, a);
       return 0;
     }
     ZT_WG(4, 4, 8);
@@ -2731,7 +2753,8 @@ static int wgrad_partial_bf16(const void* x, int ldx, const void* dz, int lddz, 
   a.x = (const zt_bf16*)x; a.dz = (const zt_bf16*)dz; a.slab = slab; a.H = H; a.W = W; a.Cin = Cin; a.ldx = ldx; a.Cout = Cout;
   a.lddz = lddz; a.mask = (const zt_bf16*)relu_mask; a.ldmask = ldmask;
   a.tilesX = zt_cdiv(W, HTW);
-  const bool nw8 = CT == 4 && NT == 4 && !(getenv("ZT_WGRAD_NW4") && atoi(getenv("ZT_WGRAD_NW4")));
+  const bool nw8 = (CT == 4 && NT == 4 && !(getenv("ZT_WGRAD_NW4") && atoi(getenv("ZT_WGRAD_NW4")))) ||
+                   (CT == 3 && NT == 3 && KW == KH && wgrad48_dma(KH, Cin, Cout, ldx, lddz));
   a.ntiles = a.tilesX * zt_cdiv(H, nw8 ? 8 : 4);      // tile rows = waves of the variant (launch_wgrad_h)
   size_t per = ((size_t)KH * KW * CT * 16 * NT * 16 + NT * 16) * sizeof(float);
   // the 8-wave variant runs one workgroup per CU: 256 slabs keep every CU busy and halve its slab traffic (measured 280 -> 266 us);
