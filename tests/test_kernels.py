@@ -660,6 +660,34 @@ def test_conv_wgrad64_dma_double_buffer(backend, nblk, ch, monkeypatch):
         assert float((res["1"][0] - res["0"][0]).abs().max()) < 2e-4 * float(w.grad.abs().max())
 
 
+@pytest.mark.parametrize("cin,ld", [(3, 8), (12, 16)])
+def test_conv_wgrad_thin48_dma_double_buffer(backend, cin, ld, monkeypatch):
+    """Thin-input (8- / 16-channel pixels) -> 48 weight gradient on the DMA kernel, several tiles per workgroup (both LDS buffers),
+    ragged tiles, garbage in the pixel's padding channels (they land in rows of the slab the reduction ignores)."""
+    import torch.nn.functional as F
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    g = torch.Generator().manual_seed(cin)
+    H, W = 43, 70
+    x = torch.randn(1, cin, H, W, generator=g).bfloat16().float()
+    dz = torch.randn(1, 48, H, W, generator=g).bfloat16().float()
+    w = torch.zeros(48, cin, 3, 3, requires_grad=True)
+    (F.conv2d(x, w, None, padding=1) * dz).sum().backward()
+    xn = _nhwc_bf16(x, ld)
+    xn[..., cin:] = 1000.0                                        # untrusted padding lanes
+    res = {}
+    for dma in ("1", "0"):
+        monkeypatch.setenv("ZT_WGRAD_DMA", dma)
+        monkeypatch.setenv("ZT_WGRAD_BLOCKS", "3")
+        gw, gb = torch.full((48, cin, 3, 3), 3.0, device=dev), torch.full((48,), 3.0, device=dev)
+        ops.conv2d_wgrad_bf16(CV(xn.to(dev), 0, cin), CV(_nhwc_bf16(dz, 48).to(dev), 0, 48), 48, 3, 3, gw, grad_b=gb)
+        res[dma] = gw.cpu()
+        assert maxerr(gw, w.grad) < 2e-3 * float(w.grad.abs().max()), (dma, maxerr(gw, w.grad))
+        assert maxerr(gb, dz.sum(dim=(0, 2, 3))) < 1e-3 * (H * W) ** 0.5
+    assert float((res["1"] - res["0"]).abs().max()) < 2e-4 * float(w.grad.abs().max())
+
+
 BF16_GEO = [
     # Cin, Cout, KH, KW, stride, pad, H, W, act, ld
     (3, 64, 7, 7, 2, (3, 3), 20, 36, None, 8),

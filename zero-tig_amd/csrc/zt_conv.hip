@@ -2189,14 +2189,18 @@ constexpr int WG64_IR = 10, WG64_IC = 34;
 template <int CH>
 __device__ __forceinline__ int wg64_swz(int col) { return CH == 64 ? (((col >> 1) & 1) | (((col >> 3) & 1) << 1)) : 0; }
 
-template <int CH>
+// CHX != CHZ (round 3): the thin-input first layers of Denoise_1/2 (Cin 3 / 12 in 8- / 16-channel pixels -> 48): one ci-tile, 9 pairs;
+// the x image has 16- or 32-byte pixels (a transposing read of an 8-channel pixel takes its upper 8 "channels" from the next pixel:
+// rows >= Cin of the product, which the slab reduction ignores, like the buffer's padding lanes).  Purely DMA / HBM bound.
+template <int CHX, int CHZ>
 __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) {
-  static_assert(CH == 64 || CH == 48, "pixel rows of 128 or 96 bytes");
-  constexpr int NW = 8, NTHR = 512, HTH = 8, IR = WG64_IR, IC = WG64_IC, CT = CH / 16, NT = CH / 16, CK = CH / 8;
+  static_assert((CHX == 64 && CHZ == 64) || (CHX == 48 && CHZ == 48) || ((CHX == 8 || CHX == 16) && CHZ == 48), "built shapes");
+  constexpr int NW = 8, NTHR = 512, HTH = 8, IR = WG64_IR, IC = WG64_IC, CT = CHX >= 16 ? CHX / 16 : 1, NT = CHZ / 16;
+  constexpr int CKX = CHX / 8, CKZ = CHZ / 8;
   constexpr int NPAIR = 9 * CT, PPW = (NPAIR + NW - 1) / NW;
-  constexpr int WG64_XE = IR * IC * CH, WG64_ZE = HTH * HTW * CH;
-  constexpr int NGX = (IR * IC * CK + NTHR - 1) / NTHR, NGZ = (HTH * HTW * CK + NTHR - 1) / NTHR;      // DMA wave-instructions per wave and tile
-  static_assert(HTH * HTW * CK % 64 == 0, "dz image = whole wave-instructions");
+  constexpr int WG64_XE = (IR * IC * CHX + 16 + 511) / 512 * 512, WG64_ZE = HTH * HTW * CHZ;       // x image + 32 B of slack, whole 1-KB pieces
+  constexpr int NGX = (IR * IC * CKX + NTHR - 1) / NTHR, NGZ = (HTH * HTW * CKZ + NTHR - 1) / NTHR;    // DMA wave-instructions per wave and tile
+  static_assert(HTH * HTW * CKZ % 64 == 0, "dz image = whole wave-instructions");
   __shared__ __attribute__((aligned(16))) zt_bf16 smem[2 * (WG64_XE + WG64_ZE)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2222,14 +2226,14 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
 #pragma unroll
   for (int i = 0; i < NGX; ++i) {
     const int e = (i * NW + wave) * 64 + lane;
-    const int p = e / CK, row = p / IC, col = p - row * IC;
-    xoff[i] = (row * a.W + col) * a.ldx + (((e - p * CK) ^ (wg64_swz<CH>(col) << 1)) * 8);
+    const int p = e / CKX, row = p / IC, col = p - row * IC;
+    xoff[i] = (row * a.W + col) * a.ldx + (((e - p * CKX) ^ (wg64_swz<CHX>(col) << 1)) * 8);
   }
 #pragma unroll
   for (int i = 0; i < NGZ; ++i) {
     const int e = (i * NW + wave) * 64 + lane;
-    const int p = e / CK, row = p / HTW, col = p - row * HTW;
-    zoff[i] = (row * a.W + col) * a.lddz + (((e - p * CK) ^ (wg64_swz<CH>(col) << 1)) * 8);
+    const int p = e / CKZ, row = p / HTW, col = p - row * HTW;
+    zoff[i] = (row * a.W + col) * a.lddz + (((e - p * CKZ) ^ (wg64_swz<CHZ>(col) << 1)) * 8);
   }
   auto dma_tile = [&](int idx, int buf) {
     int ty, tx;
@@ -2242,10 +2246,10 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
       const zt_bf16* zo = a.dz + (unsigned)((oy0 * a.W + ox0) * a.lddz);
 #pragma unroll
       for (int i = 0; i < NGX; ++i)
-        if ((i * NW + NW) * 64 <= IR * IC * CK || (i * NW + wave) * 64 + lane < IR * IC * CK) ZT_GLDS16_HIDDEN(xo + xoff[i], xb + (i * NW + wave) * 512);
+        if ((i * NW + NW) * 64 <= IR * IC * CKX || (i * NW + wave) * 64 + lane < IR * IC * CKX) ZT_GLDS16_HIDDEN(xo + xoff[i], xb + (i * NW + wave) * 512);
 #pragma unroll
       for (int i = 0; i < NGZ; ++i)
-        if ((i * NW + NW) * 64 <= HTH * HTW * CK || (i * NW + wave) * 64 < HTH * HTW * CK) ZT_GLDS16_HIDDEN(zo + zoff[i], zb + (i * NW + wave) * 512);
+        if ((i * NW + NW) * 64 <= HTH * HTW * CKZ || (i * NW + wave) * 64 < HTH * HTW * CKZ) ZT_GLDS16_HIDDEN(zo + zoff[i], zb + (i * NW + wave) * 512);
       return;
     }
     int ln = lane;
@@ -2253,24 +2257,24 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
 #pragma unroll
     for (int i = 0; i < NGX; ++i) {
       const int e = (i * NW + wave) * 64 + ln;
-      const int p = e / CK, row = p / IC, col = p - row * IC;
-      const int cj = (e - p * CK) ^ (wg64_swz<CH>(col) << 1);
+      const int p = e / CKX, row = p / IC, col = p - row * IC;
+      const int cj = (e - p * CKX) ^ (wg64_swz<CHX>(col) << 1);
       const int gy = oy0 - 1 + row, gx = ox0 - 1 + col;
       const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       const int gyc = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
       const void* src = in ? (const void*)(a.x + (unsigned)((gyc * a.W + gxc) * a.ldx + cj * 8)) : (const void*)&zt_zero_chunk;
-      if ((i * NW + NW) * 64 <= IR * IC * CK || e < IR * IC * CK) ZT_GLDS16_HIDDEN(src, xb + (i * NW + wave) * 512);
+      if ((i * NW + NW) * 64 <= IR * IC * CKX || e < IR * IC * CKX) ZT_GLDS16_HIDDEN(src, xb + (i * NW + wave) * 512);
     }
 #pragma unroll
     for (int i = 0; i < NGZ; ++i) {
       const int e = (i * NW + wave) * 64 + ln;
-      const int p = e / CK, row = p / HTW, col = p - row * HTW;
-      const int cj = (e - p * CK) ^ (wg64_swz<CH>(col) << 1);
+      const int p = e / CKZ, row = p / HTW, col = p - row * HTW;
+      const int cj = (e - p * CKZ) ^ (wg64_swz<CHZ>(col) << 1);
       const int gy = oy0 + row, gx = ox0 + col;
       const bool in = gy < a.H && gx < a.W;
       const int gyc = gy >= a.H ? a.H - 1 : gy, gxc = gx >= a.W ? a.W - 1 : gx;
       const void* src = in ? (const void*)(a.dz + (unsigned)((gyc * a.W + gxc) * a.lddz + cj * 8)) : (const void*)&zt_zero_chunk;
-      if ((i * NW + NW) * 64 <= HTH * HTW * CK || (i * NW + wave) * 64 < HTH * HTW * CK) ZT_GLDS16_HIDDEN(src, zb + (i * NW + wave) * 512);
+      if ((i * NW + NW) * 64 <= HTH * HTW * CKZ || (i * NW + wave) * 64 < HTH * HTW * CKZ) ZT_GLDS16_HIDDEN(src, zb + (i * NW + wave) * 512);
     }
   };
 
@@ -2290,16 +2294,16 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
     const int tap = pr / CT, cit = pr - tap * CT;
     const int ky = tap / 3, kx = tap - ky * 3;
     const int c0 = kx + g8 + trq, c1 = c0 + 4;
-    alo[pi] = (ky * IC + c0) * CH + ((cit ^ wg64_swz<CH>(c0)) * 16) + trp;
-    ahi[pi] = (ky * IC + c1) * CH + ((cit ^ wg64_swz<CH>(c1)) * 16) + trp;
+    alo[pi] = (ky * IC + c0) * CHX + ((cit ^ wg64_swz<CHX>(c0)) * 16) + trp;
+    ahi[pi] = (ky * IC + c1) * CHX + ((cit ^ wg64_swz<CHX>(c1)) * 16) + trp;
   }
   int blo[NT], bhi[NT];
   {
     const int c0 = g8 + trq, c1 = c0 + 4;
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
-      blo[q] = WG64_XE + c0 * CH + ((q ^ wg64_swz<CH>(c0)) * 16) + trp;
-      bhi[q] = WG64_XE + c1 * CH + ((q ^ wg64_swz<CH>(c1)) * 16) + trp;
+      blo[q] = WG64_XE + c0 * CHZ + ((q ^ wg64_swz<CHZ>(c0)) * 16) + trp;
+      bhi[q] = WG64_XE + c1 * CHZ + ((q ^ wg64_swz<CHZ>(c1)) * 16) + trp;
     }
   }
   const bool ones_slot = wave == NPAIR % NW;                     // uniform: the first wave whose last pair slot is spare = bias column sums
@@ -2334,16 +2338,16 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
     auto load_a = [&](auto bc, auto rc, auto pc) {
       constexpr int bi = decltype(bc)::value, pi = decltype(pc)::value;
       constexpr int row = decltype(rc)::value < HTH ? decltype(rc)::value : HTH - 1;
-      fal[bi] = zt_lds_read_tr16(pal[pi] + row * IC * CH);
-      fah[bi] = zt_lds_read_tr16(pah[pi] + row * IC * CH);
+      fal[bi] = zt_lds_read_tr16(pal[pi] + row * IC * CHX);
+      fah[bi] = zt_lds_read_tr16(pah[pi] + row * IC * CHX);
     };
     auto load_b = [&](auto bc, auto rc) {
       constexpr int bi = decltype(bc)::value;
       constexpr int row = decltype(rc)::value < HTH ? decltype(rc)::value : HTH - 1;
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
-        const zt_s16x4 lo = zt_lds_read_tr16(pbl[q] + row * HTW * CH);
-        const zt_s16x4 hi = zt_lds_read_tr16(pbh[q] + row * HTW * CH);
+        const zt_s16x4 lo = zt_lds_read_tr16(pbl[q] + row * HTW * CHZ);
+        const zt_s16x4 hi = zt_lds_read_tr16(pbh[q] + row * HTW * CHZ);
         bv[bi][q] = (zt_s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     };
@@ -2368,8 +2372,8 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
       __builtin_amdgcn_sched_barrier(0);
     });
   }
-  // slab of this workgroup: [tap][ci CH][co CH] + [co CH] (same layout as wgrad_mfma_bf16_kernel)
-  float* out = a.slab + (size_t)blockIdx.x * (9 * CH * CH + CH);
+  // slab of this workgroup: [tap][ci CT*16][co CHZ] + [co CHZ] (same layout as wgrad_mfma_bf16_kernel)
+  float* out = a.slab + (size_t)blockIdx.x * (9 * CT * 16 * CHZ + CHZ);
   const int l4 = lane >> 4;
 #pragma unroll
   for (int pi = 0; pi < PPW; ++pi) {
@@ -2379,12 +2383,12 @@ __global__ void __launch_bounds__(512, 1) wgrad64_dma_bf16_kernel(WgradArgsH a) 
 #pragma unroll
       for (int q = 0; q < NT; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[((size_t)tap * CH + cit * 16 + l4 * 4 + j) * CH + q * 16 + l15] = acc[pi][q][j];
+        for (int j = 0; j < 4; ++j) out[((size_t)tap * CT * 16 + cit * 16 + l4 * 4 + j) * CHZ + q * 16 + l15] = acc[pi][q][j];
     }
   }
   if (ones_slot && l4 == 0) {          // every row of the ones product holds the column sums: row 0 (lanes 0..15, register 0)
 #pragma unroll
-    for (int q = 0; q < NT; ++q) out[9 * CH * CH + q * 16 + l15] = acc[PPW - 1][q][0];
+    for (int q = 0; q < NT; ++q) out[9 * CT * 16 * CHZ + q * 16 + l15] = acc[PPW - 1][q][0];
   }
 }
 
@@ -2394,11 +2398,24 @@ static bool wgrad48_dma(int K, int Cin, int Cout, int ldx, int lddz) {
   return dma && K == 3 && Cin == 48 && Cout == 48 && ldx >= 48 && lddz >= 48 && ldx % 8 == 0 && lddz % 8 == 0;
 }
 
+// ... and the thin-input 3x3 layers with 48 couts whose pixels are exactly 8 or 16 channels wide (Denoise_1/2 conv1)
+static bool wgrad_thin48_dma(int K, int Cin, int Cout, int ldx, int lddz, const void* mask) {
+  const int dma = getenv("ZT_WGRAD_DMA") ? atoi(getenv("ZT_WGRAD_DMA")) : 1;
+  return dma && !mask && K == 3 && Cout == 48 && (ldx == 8 || ldx == 16) && Cin <= ldx && lddz >= 48 && lddz % 8 == 0;
+}
+
 template <int KH, int KW>
 int launch_wgrad_h(const WgradArgsH& a, int CT, int NT, int nblk, hipStream_t stream) {
   dim3 grid(nblk);
 #define ZT_WG(ct, nt, nw) hipLaunchKernelGGL((wgrad_mfma_bf16_kernel<KH, KW, ct, nt, nw>), grid, dim3(nw * 64), 0, stream, a); return 0
-  if (CT == 1 && NT == 3) { ZT_WG(1, 3, 4); }
+  if (CT == 1 && NT == 3) {
+    if (wgrad_thin48_dma(KH, a.Cin, a.Cout, a.ldx, a.lddz, a.mask)) {
+      if (a.ldx == 8) hipLaunchKernelGGL((wgrad64_dma_bf16_kernel<8, 48>), grid, dim3(512), 0, stream, a);
+      else hipLaunchKernelGGL((wgrad64_dma_bf16_kernel<16, 48>), grid, dim3(512), 0, stream, a);
+      return 0;
+    }
+    ZT_WG(1, 3, 4);
+  }
   if (CT == 1 && NT == 4) {
     if (a.mask) {
       hipLaunchKernelGGL((wgrad_mfma_bf16_kernel<KH, KW, 1, 4, 4, true>), grid, dim3(256), 0, stream, a);
@@ -2409,7 +2426,7 @@ int launch_wgrad_h(const WgradArgsH& a, int CT, int NT, int nblk, hipStream_t st
   if (a.mask) return ZT_EINVAL;                                  // the folded ReLU mask exists for the thin-input 64-cout layer only
   if (CT == 3 && NT == 3) {
     if (wgrad48_dma(KH, a.Cin, a.Cout, a.ldx, a.lddz)) {          // 8-row tiles, one workgroup per CU (ntiles / nblk sized for it by the caller)
-      hipLaunchKernelGGL(wgrad64_dma_bf16_kernel<48>, grid, dim3(512), 0, stream, a);
+      hipLaunchKernelGGL((wgrad64_dma_bf16_kernel<48, 48>), grid, dim3(512), 0, stream, a);
       return 0;
     }
     ZT_WG(3, 3, 4);
@@ -2421,7 +2438,7 @@ int launch_wgrad_h(const WgradArgsH& a, int CT, int NT, int nblk, hipStream_t st
     const int dma = getenv("ZT_WGRAD_DMA") ? atoi(getenv("ZT_WGRAD_DMA")) : 1;             // 0: the register-staged form (A/B: tests, tools/bench_wgrad.py)
     if (dma && KH == 3 && KW == 3 && a.Cin == 64 && a.Cout == 64 && a.ldx >= 64 && a.lddz >= 64 && a.ldx % 8 == 0 && a.lddz % 8 == 0 &&
         a.ntiles % a.tilesX == 0) {
-      hipLaunchKernelGGL(wgrad64_dma_bf16_kernel<64>, grid, dim3(512), 0, stream, a);
+      hipLaunchKernelGGL((wgrad64_dma_bf16_kernel<64, 64>), grid, dim3(512), 0, stream, a);
       return 0;
     }
     ZT_WG(4, 4, 8);
@@ -2754,7 +2771,8 @@ static int wgrad_partial_bf16(const void* x, int ldx, const void* dz, int lddz, 
   a.lddz = lddz; a.mask = (const zt_bf16*)relu_mask; a.ldmask = ldmask;
   a.tilesX = zt_cdiv(W, HTW);
   const bool nw8 = (CT == 4 && NT == 4 && !(getenv("ZT_WGRAD_NW4") && atoi(getenv("ZT_WGRAD_NW4")))) ||
-                   (CT == 3 && NT == 3 && KW == KH && wgrad48_dma(KH, Cin, Cout, ldx, lddz));
+                   (CT == 3 && NT == 3 && KW == KH && wgrad48_dma(KH, Cin, Cout, ldx, lddz)) ||
+                   (CT == 1 && NT == 3 && KW == KH && wgrad_thin48_dma(KH, Cin, Cout, ldx, lddz, relu_mask));
   a.ntiles = a.tilesX * zt_cdiv(H, nw8 ? 8 : 4);      // tile rows = waves of the variant (launch_wgrad_h)
   size_t per = ((size_t)KH * KW * CT * 16 * NT * 16 + NT * 16) * sizeof(float);
   // the 8-wave variant runs one workgroup per CU: 256 slabs keep every CU busy and halve its slab traffic (measured 280 -> 266 us);
