@@ -108,6 +108,9 @@ int zt_partial_reduce_f32(const float* partial, int nblk, int stride, int n, flo
 /* one launch for a BatchNorm layer's backward sums: sums[0:2C] = column sums of partial [nblk][2][C]; dbeta += sums[0:C],
    dgamma += sums[C:2C] (torch BatchNorm2d backward, reference model.py:60-67 through autograd) */
 int zt_bn_bwd_sums_f32(const float* partial, int nblk, int C, float* dbeta, float* dgamma, float* sums, zt_stream_t stream);
+/* same for partials whose second half is sum g (z - mean) (zt_conv3x3_dgrad_bn_sums_bf16): multiplied by rstd on the way */
+int zt_bn_bwd_sums_centered_f32(const float* partial, int nblk, int C, const float* rstd, float* dbeta, float* dgamma, float* sums,
+                                zt_stream_t stream);
 int zt_bn_bwd_apply(const void* dy, int dt, int lddy, const void* z, int ldz, const float* scale, const float* shift,
                         const float* mean, const float* rstd, const float* sums, void* dz, int lddz, int HW, int C,
                         int eval_mode, zt_stream_t stream);
@@ -281,6 +284,14 @@ int zt_conv2d_nhwc_bf16_ex(const void* x, const void* x2, int csplit, int ldx, i
  * the convolution followed by the statistics kernel (same output contract). */
 int zt_conv3x3_bn_stats_bf16(const void* x, int ldx, int H, int W, int Cin, const void* w, int CoutP, int ldk, const float* bias,
                              void* y, int ldy, int Cout, float* stats, int stats_blocks, zt_stream_t stream);
+/* Enhancer block backward (autograd of model.py:60-67): df = conv3x3^T(dz) + res (the data gradient with the residual add, wT = the
+ * flipped / transposed weights, all bf16 nhwc with 64 channels, N == 1) AND, in the same pass, the BatchNorm-backward sums of the
+ * block BELOW, whose output gradient df is: g = df * [bn_scale * zprev + bn_shift > 0] (its ReLU), stats [512][2][64] = per-workgroup
+ * (sum g, sum g (zprev - bn_mean)), zero beyond the launch's workgroups -- feed to zt_bn_bwd_sums_centered_f32(nblk = 512).
+ * Replaces zt_conv2d_nhwc_bf16 (epi 3) + zt_bn_bwd_reduce. */
+int zt_conv3x3_dgrad_bn_sums_bf16(const void* dz, int lddz, int H, int W, const void* wT, int CoutP, int ldk, void* df, int lddf,
+                                  const void* res, int ldres, const void* zprev, int ldz, const float* bn_scale, const float* bn_shift,
+                                  const float* bn_mean, float* stats, int stats_blocks, zt_stream_t stream);
 /* relu_mask (optional, thin-input 3x3 layer with 64 couts): dz is taken as dz * [relu_mask > 0], i.e. the backward of the ReLU
  * that follows the layer (model.py:55-56) is folded into the staging of dz instead of a separate masking pass */
 int zt_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, int H, int W, int Cin, int Cout, int KH, int KW,

@@ -780,6 +780,42 @@ def test_conv3x3_bn_stats_bf16(backend, force_fused, monkeypatch):
     assert maxerr(rstd, 1.0 / torch.sqrt(got.double().var(dim=(0, 2, 3), unbiased=False) + 1e-5).view(1, 64)) < 1e-4
 
 
+def test_conv3x3_dgrad_bn_sums_bf16(backend):
+    """Enhancer block backward: data gradient + residual with the BatchNorm-backward sums of the block below accumulated in the
+    same kernel's store phase == the plain data gradient (bit-identical output) followed by the stand-alone reduce pass
+    (zt_bn_bwd_reduce) on that output; 19 x 37: ragged tiles.  And the whole bn_relu_bwd with / without the fused partials."""
+    from importlib import import_module
+    CV = import_module("zero-tig_amd.ops").CV
+    ops, dev, _ = backend
+    g = torch.Generator().manual_seed(21)
+    H, W = 19, 37
+    mk = lambda s=1.0: _nhwc_bf16(torch.randn(1, 64, H, W, generator=g) * s, 64).to(dev)
+    dz, res, zprev = mk(), mk(), mk(2.0)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    wT = ops.repack_weight_bf16(w.to(dev), transpose_flip=True)
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.3).to(dev)
+    zf = zprev.float()
+    mean = zf.mean(dim=(0, 1, 2))
+    rstd = 1.0 / torch.sqrt(zf.var(dim=(0, 1, 2), unbiased=False) + 1e-5)
+    scale, shift = (gamma * rstd).contiguous(), (beta - mean * gamma * rstd).contiguous()
+    df, part = ops.conv3x3_dgrad_bn_sums_bf16(dz, wT, res, zprev, scale, shift, mean.contiguous())
+    ref_df = ops.conv2d_bf16(CV(dz), wT, None, 64, 3, 3, (1, 1), None, aux=res, epi=3, variant=3)
+    assert torch.equal(df.cpu(), ref_df.cpu())
+    # sums of the STORED gradient, masked by the block's ReLU, plain and against the centred pre-activation
+    dff, m = df.float().cpu().double(), (zf * scale + shift > 0).cpu()
+    gm = torch.where(m, dff, torch.zeros_like(dff))
+    s = part.cpu().double().sum(dim=0)
+    assert float((s[0] - gm.sum(dim=(0, 1, 2))).abs().max()) < 1e-3 * (H * W) ** 0.5
+    assert float((s[1] - (gm * (zf.cpu().double() - mean.cpu().double())).sum(dim=(0, 1, 2))).abs().max()) < 2e-3 * (H * W) ** 0.5
+    outs = []
+    for p in (part, None):
+        dg, db = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+        o = ops.bn_relu_bwd(df, zprev, scale, shift, mean.contiguous(), rstd.contiguous(), dg, db, part=p)
+        outs.append((o.float().cpu(), dg.cpu(), db.cpu()))
+    assert maxerr(outs[0][1], outs[1][1]) < 1e-3 * (H * W) ** 0.5 and maxerr(outs[0][2], outs[1][2]) < 1e-3 * (H * W) ** 0.5
+    assert maxerr(outs[0][0], outs[1][0]) < 2e-2          # bf16 outputs: a last-bit difference of the sums moves an element by one bf16 ulp
+
+
 @pytest.mark.parametrize("cin,with_bias", [(3, False), (6, False), (6, True)], ids=["c3-plain", "c6-plain", "c6-generic"])
 def test_conv1x1_thin_input_bf16(backend, cin, with_bias):
     """Data gradient of Denoise_1/2's 1x1 output layer (3/6 -> 48 channels, LeakyReLU-mask epilogue): the streaming thin-input

@@ -488,6 +488,13 @@ struct ConvArgsH {
   zt_bf16* y2;                 // epi 4: second destination (r * h), channels [esplit, Cout) go there
   int ldy2, esplit;
   float* stats;                // conv_rs STATS: per-workgroup (sum, sum of squares) of the stored outputs, [grid][2][Cout]
+  // conv_rs BSTATS (data gradient + residual of an Enhancer block): the BatchNorm backward sums of the PREVIOUS block, whose output
+  // gradient this launch produces -- g = out * [bn_scale * zprev + bn_shift > 0]; stats[grid][2][Cout] = (sum g, sum g (zprev - bn_mean))
+  const zt_bf16* zprev;
+  int ldz;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
 };
 
 constexpr int HCK = 32;                 // channel granularity of a two-part (split) input
@@ -1442,7 +1449,9 @@ __device__ __forceinline__ zt_f32x4 zt_mfma_bf16_k16(zt_s16x4 a, zt_s16x4 b, zt_
 // zt_norm_finalize_f32 reduces the [grid][2][Cout] partials.  Replaces a separate 265 MB read pass per Enhancer block.
 template <int NQ, int NM, bool COSPLIT, int C32, int C16, bool EPI, int RT, bool STATS = false>
 __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(ConvArgsH a, int ntiles) {
-  static_assert(!STATS || (!EPI && RT == 4), "statistics are fused into the plain 4-row forward variant");
+  static_assert(!STATS || RT == 4, "statistics are fused into the 4-row variants");
+  static_assert(!STATS || !EPI || COSPLIT, "backward statistics ride in the 64-cout data-gradient variant (aux fetched by the store phase)");
+  constexpr bool BSTATS = STATS && EPI;                         // BatchNorm-backward sums instead of forward statistics
   constexpr int RTH = RT, NTHR = 64 * RT, NST = RT == 8 ? 2 : 1;
   // fused aux operand (activation mask / residual): the 8-row form DMAs its tile into the idle staging buffer (AUXL); the 4-row
   // form has no second staging buffer and reads it in accumulator layout (8 bytes per lane and 16x16 block) half a loop ahead
@@ -1466,12 +1475,16 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
   __shared__ __attribute__((aligned(16))) zt_bf16 st[NST][RTH * TW * CW];
   __shared__ float bias_s[CW];
   __shared__ __attribute__((aligned(16))) float stat_s[STATS ? RT * 2 * CW : 4];      // [wave][octet][sum 8 | sumsq 8]
+  __shared__ __attribute__((aligned(16))) float bn_s[BSTATS ? 3 * CW : 4];             // BSTATS: [scale | shift | mean][channel]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int rp = wave >> 1, sel = wave & 1;
   if constexpr (STATS) {
     for (int e = tid; e < RT * 2 * CW; e += NTHR) stat_s[e] = 0.f;
+  }
+  if constexpr (BSTATS) {
+    for (int e = tid; e < 3 * CW; e += NTHR) bn_s[e] = e < CW ? a.bn_scale[e] : (e < 2 * CW ? a.bn_shift[e - CW] : a.bn_mean[e - 2 * CW]);
   }
   const int q0 = COSPLIT ? sel * NQ : 0, m0 = COSPLIT ? 0 : sel;
 
@@ -1647,7 +1660,7 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
       if (halo_in_flight) zt_wait_vmcnt<GLDS ? NGL : NPF>();
       else zt_wait_vmcnt0();
     }
-    uint4 v[NOUT], ux[AUXS ? NOUT : 1];
+    uint4 v[NOUT], ux[AUXS ? NOUT : 1], zx[BSTATS ? NOUT : 1];
     float ssum[STATS ? 8 : 1], ssq[STATS ? 8 : 1];
     if constexpr (STATS) {
 #pragma unroll
@@ -1661,6 +1674,7 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
         oy = oy >= a.Ho ? a.Ho - 1 : oy;
         ox = ox >= a.Wo ? a.Wo - 1 : ox;
         ux[AUXS ? i : 0] = *reinterpret_cast<const uint4*>(a.aux + (unsigned)((oy * a.Wo + ox) * a.ldaux + ch * 8));
+        if constexpr (BSTATS) zx[BSTATS ? i : 0] = *reinterpret_cast<const uint4*>(a.zprev + (unsigned)((oy * a.Wo + ox) * a.ldz + ch * 8));
       }
     }
     if (!AUXL) {                                                // AUXL runs mid-loop with every accumulator live: one chunk at a time
@@ -1700,7 +1714,7 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
         o = v[i];
       }
       if (oy < a.Ho && ox < a.Wo) *reinterpret_cast<uint4*>((zt_bf16*)a.y + (unsigned)((oy * a.Wo + ox) * a.ldy + ch * 8)) = o;
-      if constexpr (STATS) {
+      if constexpr (STATS && !BSTATS) {
         if (oy < a.Ho && ox < a.Wo) {
           const unsigned ow[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
@@ -1710,6 +1724,30 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
             ssum[2 * j + 1] += f1;
             ssq[2 * j] += f0 * f0;
             ssq[2 * j + 1] += f1 * f1;
+          }
+        }
+      }
+      if constexpr (BSTATS) {
+        // the stored (bf16-rounded) gradient of the previous block's output, masked by that block's ReLU, summed plain and against
+        // its centred pre-activation: what zt_bn_bwd_reduce computes in a pass of its own over the same two tensors
+        if (oy < a.Ho && ox < a.Wo) {
+          const unsigned ow[4] = {o.x, o.y, o.z, o.w};
+          const uint4 zq = zx[BSTATS ? i : 0];
+          const unsigned zw[4] = {zq.x, zq.y, zq.z, zq.w};
+          const float4 sa = *reinterpret_cast<const float4*>(bn_s + ch * 8), sb2 = *reinterpret_cast<const float4*>(bn_s + ch * 8 + 4);
+          const float4 ha = *reinterpret_cast<const float4*>(bn_s + CW + ch * 8), hb = *reinterpret_cast<const float4*>(bn_s + CW + ch * 8 + 4);
+          const float4 ma = *reinterpret_cast<const float4*>(bn_s + 2 * CW + ch * 8), mb = *reinterpret_cast<const float4*>(bn_s + 2 * CW + ch * 8 + 4);
+          const float scv[8] = {sa.x, sa.y, sa.z, sa.w, sb2.x, sb2.y, sb2.z, sb2.w}, shv[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+          const float muv[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float f0 = zt_u2f(ow[j] << 16), f1 = zt_u2f(ow[j] & 0xFFFF0000u);
+            const float z0 = zt_u2f(zw[j] << 16), z1 = zt_u2f(zw[j] & 0xFFFF0000u);
+            const float g0 = z0 * scv[2 * j] + shv[2 * j] > 0.f ? f0 : 0.f, g1 = z1 * scv[2 * j + 1] + shv[2 * j + 1] > 0.f ? f1 : 0.f;
+            ssum[2 * j] += g0;
+            ssum[2 * j + 1] += g1;
+            ssq[2 * j] += g0 * (z0 - muv[2 * j]);
+            ssq[2 * j + 1] += g1 * (z1 - muv[2 * j + 1]);
           }
         }
       }
@@ -1891,12 +1929,13 @@ int launch_conv_rs(ConvArgsH& a, hipStream_t stream) {
   const int maxg = rt == 4 ? 512 : 256;
   dim3 grid(ntiles < maxg ? ntiles : maxg), block(64 * rt);
   const int kc = a.Cin <= 16 ? 0 : (a.Cin > 48 ? 2 : 1);       // 0: one K=16 chunk, 1: 32 + 16, 2: 32 + 32
-  if (a.stats) {                                                // fused BatchNorm statistics: the 64 -> 64 forward layer, 4-row tiles
-    if (!(a.Cout == 64 && kc == 2 && !a.epi)) return ZT_EINVAL;
+  if (a.stats) {                                                // fused BatchNorm statistics: the 64 -> 64 layer, 4-row tiles
+    if (!(a.Cout == 64 && kc == 2 && (!a.epi || (a.epi == 3 && a.zprev)))) return ZT_EINVAL;
     a.tilesY = zt_cdiv(a.Ho, 4);
     const int nt4 = a.tilesX * a.tilesY;
     dim3 g4(nt4 < 512 ? nt4 : 512);
-    hipLaunchKernelGGL((conv_rs_bf16_kernel<2, 2, true, 2, 0, false, 4, true>), g4, dim3(256), 0, stream, a, nt4);
+    if (a.epi) hipLaunchKernelGGL((conv_rs_bf16_kernel<2, 2, true, 2, 0, true, 4, true>), g4, dim3(256), 0, stream, a, nt4);      // data gradient + residual + BN-backward sums
+    else hipLaunchKernelGGL((conv_rs_bf16_kernel<2, 2, true, 2, 0, false, 4, true>), g4, dim3(256), 0, stream, a, nt4);           // forward + BN statistics
     return 0;
   }
 #define ZT_RS(nq, nm, cs, c32, c16)                                                                                            \
@@ -2563,11 +2602,17 @@ extern "C" int zt_repack_conv_weight_f32(const float* src, float* dst, int Cout,
 }
 
 // variant: 0 = choose by problem size, 1 = force the persistent weight-stationary kernel, 2 = force the tiled kernel
+struct BnBwdFuse {             // zt_conv3x3_dgrad_bn_sums_bf16: the previous block's pre-activation and BatchNorm constants
+  const void* zprev;
+  int ldz;
+  const float *scale, *shift, *mean;
+};
+
 static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,
                             const void* w, int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode,
                             int Cout, int KH, int KW, int stride, int padH, int padW, int act, float alpha,
                             const void* aux, int ldaux, int epi, int variant, void* y2, int ldy2, int esplit, hipStream_t stream,
-                            float* stats = nullptr) {
+                            float* stats = nullptr, const BnBwdFuse* bnb = nullptr) {
   ZT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && out_mode >= 0 && out_mode <= 2);
   ZT_REQUIRE(epi >= 0 && epi <= 5 && (epi < 4 || (out_mode == 0 && variant == 2)) && (epi != 4 || (y2 && esplit > 0 && esplit < Cout)));
   ZT_REQUIRE(ldx % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
@@ -2581,6 +2626,8 @@ static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, 
   a.Cout = Cout; a.CoutP = CoutP; a.ldk = ldk; a.ldy = ldy; a.ldaux = ldaux;
   a.padH = padH; a.padW = padW; a.act = act; a.epi = epi; a.out_mode = out_mode; a.alpha = alpha;
   a.y2 = (zt_bf16*)y2; a.ldy2 = ldy2; a.esplit = esplit; a.stats = stats;
+  a.zprev = nullptr; a.ldz = 0; a.bn_scale = a.bn_shift = a.bn_mean = nullptr;
+  if (bnb) { a.zprev = (const zt_bf16*)bnb->zprev; a.ldz = bnb->ldz; a.bn_scale = bnb->scale; a.bn_shift = bnb->shift; a.bn_mean = bnb->mean; }
   static const int scalar_epi = getenv("ZT_TILED_SCALAR_EPI") ? atoi(getenv("ZT_TILED_SCALAR_EPI")) : 0;   // A/B knob: per-element epilogue
   a.dbg = (variant >= 64 ? (variant - 64) : (variant >= 32 ? (variant - 32) : (variant >= 16 ? (variant - 16) : 0))) | (scalar_epi ? 32 : 0);   // tuning ablations, see tools/bench_conv.py / bench_small.py
   if (variant >= 64) variant = 2;
@@ -2703,6 +2750,7 @@ extern "C" int zt_conv2d_pair_nhwc_bf16(const void* xA, int ldxA, int CinA, cons
     c.Ho = H; c.Wo = W; c.Cout = Cout[i]; c.CoutP = CoutP[i]; c.ldk = ldk[i]; c.ldy = ldy[i]; c.ldaux = 0;
     c.padH = Ks[i] / 2; c.padW = Ks[i] / 2; c.act = act; c.epi = 0; c.out_mode = 0; c.dbg = 0; c.alpha = 1.f;
     c.tilesX = tilesX; c.tilesY = tilesY; c.y2 = nullptr; c.ldy2 = 0; c.esplit = 0; c.stats = nullptr;
+    c.zprev = nullptr; c.ldz = 0; c.bn_scale = c.bn_shift = c.bn_mean = nullptr;
     ZT_REQUIRE(((uintptr_t)c.x & 15) == 0 && ((uintptr_t)c.w & 15) == 0 && c.ldk % 8 == 0 && ((uintptr_t)c.y & 15) == 0);
   }
   const dim3 grid(tilesX, gA + gB, tilesY);
@@ -2749,6 +2797,18 @@ extern "C" int zt_conv3x3_bn_stats_bf16(const void* x, int ldx, int H, int W, in
   const int HW = H * W;
   int nblk = HW / 64 < 1 ? 1 : (HW / 64 > stats_blocks ? stats_blocks : HW / 64);
   return zt_chan_stats_nhwc(y, 1, ldy, 1, HW, Cout, nblk, stats, stream);
+}
+
+extern "C" int zt_conv3x3_dgrad_bn_sums_bf16(const void* dz, int lddz, int H, int W, const void* wT, int CoutP, int ldk, void* df, int lddf,
+                                             const void* res, int ldres, const void* zprev, int ldz, const float* bn_scale,
+                                             const float* bn_shift, const float* bn_mean, float* stats, int stats_blocks, hipStream_t stream) {
+  ZT_REQUIRE(dz && wT && df && res && zprev && bn_scale && bn_shift && bn_mean && stats && stats_blocks == 512);
+  ZT_REQUIRE(ldz % 8 == 0 && ((uintptr_t)zprev & 15) == 0 && (long long)zt_cdiv(W, TW) * zt_cdiv(H, 4) >= 1);
+  hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * (size_t)stats_blocks * 2 * 64, stream);      // rows beyond the launch's workgroups stay zero
+  if (e != hipSuccess) return (int)e;
+  BnBwdFuse b = {zprev, ldz, bn_scale, bn_shift, bn_mean};
+  return conv2d_bf16_impl(dz, nullptr, 0, lddz, 0, 1, H, W, 64, wT, CoutP, ldk, nullptr, df, lddf, 0, 64, 3, 3, 1, 1, 1, 0, 1.f, res, ldres, 3, 3, nullptr, 0,
+                          0, stream, stats, &b);
 }
 
 extern "C" int zt_conv2d_nhwc_bf16(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin,

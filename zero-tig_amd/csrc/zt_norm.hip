@@ -277,9 +277,11 @@ __global__ void __launch_bounds__(256) partial_reduce_kernel(const float* __rest
 
 // BatchNorm backward: the three column sums one layer needs from its [nblk][2][C] partials in one launch --
 // sums[0:2C] = (sum dyh, sum dyh*zhat), dbeta += sums[0:C], dgamma += sums[C:2C].  Same summation as partial_reduce_kernel.
+// rstd != NULL: the second half of the partials holds sum g (z - mean) (the data-gradient kernel's fused form), converted here to
+// sum g xhat = rstd * sum g (z - mean)
 __global__ void __launch_bounds__(256) bn_bwd_sums_kernel(const float* __restrict__ partial, int nblk, int C,
                                                           float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                                          float* __restrict__ sums) {
+                                                          float* __restrict__ sums, const float* __restrict__ rstd) {
   __shared__ double sh[256];
   const int j = blockIdx.x;
   double s = 0.0;
@@ -291,7 +293,8 @@ __global__ void __launch_bounds__(256) bn_bwd_sums_kernel(const float* __restric
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const float v = (float)sh[0];
+    float v = (float)sh[0];
+    if (rstd && j >= C) v *= rstd[j - C];
     sums[j] = v;
     if (j < C) dbeta[j] += v;
     else dgamma[j - C] += v;
@@ -598,7 +601,15 @@ extern "C" int zt_partial_reduce_f32(const float* partial, int nblk, int stride,
 extern "C" int zt_bn_bwd_sums_f32(const float* partial, int nblk, int C, float* dbeta, float* dgamma, float* sums,
                                   hipStream_t stream) {
   ZT_REQUIRE(partial && nblk > 0 && C > 0 && dbeta && dgamma && sums);
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(2 * C), dim3(256), 0, stream, partial, nblk, C, dbeta, dgamma, sums);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(2 * C), dim3(256), 0, stream, partial, nblk, C, dbeta, dgamma, sums, (const float*)nullptr);
+  ZT_LAUNCH_CHECK();
+  return ZT_OK;
+}
+
+extern "C" int zt_bn_bwd_sums_centered_f32(const float* partial, int nblk, int C, const float* rstd, float* dbeta, float* dgamma, float* sums,
+                                           hipStream_t stream) {
+  ZT_REQUIRE(partial && nblk > 0 && C > 0 && rstd && dbeta && dgamma && sums);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(2 * C), dim3(256), 0, stream, partial, nblk, C, dbeta, dgamma, sums, rstd);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

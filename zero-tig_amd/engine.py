@@ -15,6 +15,7 @@ TERM_NAMES = ["enh_s2", "enh_norm", "smooth", "tv", "res1_a", "res1_b", "res1_c"
 
 import os
 
+_FUSED_BN_BWD = os.environ.get("ZT_FUSED_BN_BWD", "1") == "1"          # A/B knob: 0 = separate BatchNorm-backward reduce pass per block
 _FUSED_THIN_BWD = os.environ.get("ZT_FUSED_THIN_BWD", "1") == "1"      # A/B knob: 0 = separate 1x1 data-gradient and weight-gradient launches
 
 D1 = "denoise_1"
@@ -229,13 +230,23 @@ class Engine:
         dOv = CV(dO, 0, 3)
         self._wgrad(feats[3], dOv, 3, 3, "enhance.out_conv.0")
         df = self._conv(dOv, "enhance.out_conv.0/T", None, 64, 3, None)
+        part = None
+        min_tiles = int(os.environ.get("ZT_STATS_FUSE_MIN_TILES", "1024"))      # same size gate as the forward statistics fusion (tests lower it)
+        fuse = self.dt and _FUSED_BN_BWD and ((W + 31) // 32) * ((H + 7) // 8) >= min_tiles
         for i in (2, 1, 0):
             sc, sh, mu, rs = stats[i]
             # eval-mode BN (the reference trains epochs >= 1 like this, train.py:138 / SURVEY A-14): running stats are constants
             dz = o.bn_relu_bwd(df, zs[i], sc, sh, mu, rs, g["enhance.conv.1.weight"], g["enhance.conv.1.bias"],
-                               eval_mode=not self.training)
+                               eval_mode=not self.training, part=part)
             self._wgrad(feats[i], dz, 64, 3, "enhance.conv.0")
-            df = self._conv(dz, "enhance.conv.0/T", None, 64, 3, None, aux=df, epi=3)
+            if fuse and i > 0:
+                # the data gradient also reduces the NEXT block's BatchNorm-backward sums (it writes that block's output gradient):
+                # one 531 MB read pass less per block
+                psc, psh, pmu, _ = stats[i - 1]
+                df, part = o.conv3x3_dgrad_bn_sums_bf16(dz, wd["enhance.conv.0/T"], df, zs[i - 1], psc, psh, pmu)
+            else:
+                df = self._conv(dz, "enhance.conv.0/T", None, 64, 3, None, aux=df, epi=3)
+                part = None
         # through the in_conv ReLU (its input needs no gradient, so only the weight gradient consumes the masked df)
         if self.dt:         # bf16: the mask [feats[0] > 0] is applied while the weight-gradient kernel stages df
             self._wgrad(CV(u, 0, 9), df, 64, 3, "enhance.in_conv.0", relu_mask=feats[0])

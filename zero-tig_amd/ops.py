@@ -362,17 +362,21 @@ class Ops:
     def partial_reduce(self, part, nblk, stride, n, out=None, accumulate=False, out2=None):
         self.lib.call("zt_partial_reduce_f32", part, nblk, stride, n, out, int(accumulate), out2, self._s(part))
 
-    def bn_relu_bwd(self, dy, z, scale, shift, mean, rstd, dgamma, dbeta, out=None, eval_mode=False):
+    def bn_relu_bwd(self, dy, z, scale, shift, mean, rstd, dgamma, dbeta, out=None, eval_mode=False, part=None):
         """backward of ReLU(BN(z)) for N == 1 (train-mode batch statistics, or eval_mode: running statistics are constants);
-        accumulates dgamma/dbeta; returns dz (NHWC)."""
+        accumulates dgamma/dbeta; returns dz (NHWC).  part: the reduce pass's partials as produced by the data-gradient kernel that
+        wrote dy (`conv3x3_dgrad_bn_sums_bf16`: [nblk][2][C] = (sum g, sum g (z - mean))) -- the separate reduce launch is skipped."""
         dy, z = _cv(dy), _cv(z)
         HW, C = z.H * z.W, z.C
-        nblk = self._nblk(HW)
-        part = torch.empty((nblk, 2, C), dtype=torch.float32, device=z.t.device)
         assert dy.t.dtype == z.t.dtype
-        self.lib.call("zt_bn_bwd_reduce", dy.ptr, _dt(z.t), dy.ld, z.ptr, z.ld, scale, shift, mean, rstd, HW, C, nblk, part, self._s(z.t))
         sums = torch.empty((2, C), dtype=torch.float32, device=z.t.device)
-        self.lib.call("zt_bn_bwd_sums_f32", part, nblk, C, dbeta, dgamma, sums, self._s(z.t))
+        if part is not None:
+            self.lib.call("zt_bn_bwd_sums_centered_f32", part, part.shape[0], C, rstd, dbeta, dgamma, sums, self._s(z.t))
+        else:
+            nblk = self._nblk(HW)
+            part = torch.empty((nblk, 2, C), dtype=torch.float32, device=z.t.device)
+            self.lib.call("zt_bn_bwd_reduce", dy.ptr, _dt(z.t), dy.ld, z.ptr, z.ld, scale, shift, mean, rstd, HW, C, nblk, part, self._s(z.t))
+            self.lib.call("zt_bn_bwd_sums_f32", part, nblk, C, dbeta, dgamma, sums, self._s(z.t))
         if out is None:
             out = torch.empty((1, z.H, z.W, C), dtype=z.t.dtype, device=z.t.device)
         o = _cv(out)
@@ -588,6 +592,20 @@ class Ops:
                       I(*[e[0].shape[0] for e in entries]), I(*[e[0].shape[1] for e in entries]), I(*[e[0].shape[2] for e in entries]),
                       I(*[e[1].shape[1] for e in entries]), I(*[e[1].shape[2] for e in entries]), I(*[int(e[2]) for e in entries]),
                       current_stream(dev))
+
+    def conv3x3_dgrad_bn_sums_bf16(self, dz, wT, res, zprev, scale, shift, mean):
+        """Enhancer block backward: df = conv3x3^T(dz) + res and the BatchNorm-backward partial sums of the block below (whose
+        pre-activation is zprev, BatchNorm constants scale / shift / mean) in one pass.  -> (df bf16 [1,H,W,64], part [512,2,64])."""
+        dz, res, zp = _cv(dz), _cv(res), _cv(zprev)
+        assert dz.t.dtype == res.t.dtype == zp.t.dtype == wT.dtype == torch.bfloat16 and dz.N == 1 and dz.C == 64 and zp.C == 64 and res.C == 64
+        dev = dz.t.device
+        df = torch.empty((1, dz.H, dz.W, 64), dtype=torch.bfloat16, device=dev)
+        part = torch.empty((512, 2, 64), dtype=torch.float32, device=dev)
+        tok = self._ev_begin(self.profile["match"].get((3, 3, 1, 64, 64, dz.H, dz.W))) if self.profile else None
+        self.lib.call("zt_conv3x3_dgrad_bn_sums_bf16", dz.ptr, dz.ld, dz.H, dz.W, wT, wT.shape[1], wT.shape[2], df, 64, res.ptr, res.ld,
+                      zp.ptr, zp.ld, scale, shift, mean, part, 512, self._s(dz.t))
+        self._ev_end(tok)
+        return df, part
 
     def conv3x3_bn_stats_bf16(self, x, wdev, bias, Cout):
         """y = conv3x3(x) + bias (bf16 nhwc) together with the BatchNorm statistics of y: -> (y, partial [1, 512, 2, Cout])."""
