@@ -220,9 +220,11 @@ int zt_axpy_dev_f32(float* y, const float* x, const float* alpha, long long n, z
 /* ---- RAFT encoder stem in bf16 mode (zt_stem.hip): conv 7x7 / stride 2 / pad 3, 3 -> 64 (extractor.py:120, 168-170).
  * x: nhwc [N][H][W][8] bf16, channels 0..2 valid and 3..7 ZERO (as zt_raft_pack_input / zt_raft_pack_pair write them);
  * w: zt_repack_stem_weight_bf16 of the torch weight [64][3][7][7] -> [7][64][64] bf16; y: nhwc [N][H/2][W/2][ldy >= 64] bf16
- * = conv + bias (the norm / ReLU that follow are separate, as in the generic path). */
+ * = conv + bias, then ReLU when relu != 0 (context encoder: the frozen BatchNorm `norm1` folded into w / bias by the caller, so
+ * relu(norm1(conv1(x))) of extractor.py:168-170 is this one launch; the feature encoder's InstanceNorm stays a separate pass). */
 int zt_repack_stem_weight_bf16(const float* src, void* dst, zt_stream_t stream);
-int zt_raft_stem_conv_bf16(const void* x, int N, int H, int W, const void* w, const float* bias, void* y, int ldy, zt_stream_t stream);
+int zt_raft_stem_conv_bf16(const void* x, int N, int H, int W, const void* w, const float* bias, void* y, int ldy, int relu,
+                           zt_stream_t stream);
 
 
 /* ---- output side (zt_io.hip): predict.py:57-61 save_images and evals.py:83-85 PSNR on the device -------------------------
@@ -272,7 +274,9 @@ int zt_conv2d_pair_nhwc_bf16(const void* xA, int ldxA, int CinA, const void* wA,
 int zt_conv2d_nhwc_bf16_variant(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin, const void* w,
                                 int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout, int KH, int KW, int stride,
                                 int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi, int variant, zt_stream_t stream);
-/* bf16 twin of zt_conv2d_nhwc_f32_ex (epi 4 / 5: bf16 nhwc outputs, tiled kernel) */
+/* bf16 twin of zt_conv2d_nhwc_f32_ex (epi 4 / 5: bf16 nhwc outputs, tiled kernel), plus
+ * epi 6: y = relu(act(conv + bias) + aux) -- the tail of a RAFT ResidualBlock whose eval-mode BatchNorm is folded into the
+ *        conv's weights and bias (model/RAFT/extractor.py:45-56: `y = relu(norm2(conv2(y))); return relu(x + y)`) */
 int zt_conv2d_nhwc_bf16_ex(const void* x, const void* x2, int csplit, int ldx, int ldx2, int N, int H, int W, int Cin, const void* w,
                            int CoutP, int ldk, const float* bias, void* y, int ldy, int out_mode, int Cout, int KH, int KW, int stride,
                            int padH, int padW, int act, float alpha, const void* aux, int ldaux, int epi, void* y2, int ldy2, int esplit,

@@ -130,6 +130,34 @@ def test_raft_flow_golden(backend, synth):
     assert float(np.abs(flow_up.cpu().numpy() - g["flow_up"]).max()) < 4e-3
 
 
+def test_raft_context_encoder_bn_fold(backend, synth, monkeypatch):
+    """bf16 plan: the context encoder's eval-mode BatchNorms folded into the convs in front of them (+ ReLU / residual epilogues,
+    extractor.py:45-56) against the same plan with separate normalisation passes and against the fp32 plan."""
+    ops, dev, bname = backend
+    raft = importlib.import_module("zero-tig_amd.raft")
+    st = synth.make_state(5)
+    for k in list(st.keys()):           # non-trivial frozen statistics
+        if k.startswith("raft.cnet") and k.endswith("running_mean"):
+            st[k][:] = synth.normal(k, st[k].shape, 0.0, 0.2, 3)
+        if k.startswith("raft.cnet") and k.endswith("running_var"):
+            st[k][:] = synth.uniform(k, st[k].shape, 0.3, 1.5, 3)
+    W = {k: torch.from_numpy(np.array(v)).to(dev) for k, v in st.items() if k.startswith("raft.")}
+    h, w = 48, 64
+    x = torch.from_numpy(synth.uniform("cx", (1, h, w, 8), -1.0, 1.0, 11)).to(dev)
+    x[..., 3:] = 0
+    outs = {}
+    for mode in ("fold", "plain", "fp32"):
+        monkeypatch.setenv("ZT_RAFT_FOLD_BN", "0" if mode == "plain" else "1")
+        plan = raft.RaftPlan(ops, W, dev, precision="fp32" if mode == "fp32" else "bf16")
+        assert bool(plan.folded) == (mode == "fold")
+        xin = x if mode == "fp32" else x.to(torch.bfloat16)
+        outs[mode] = plan._encoder("cnet", xin.contiguous(), "batch").float().cpu()
+    assert outs["fold"].shape == outs["plain"].shape == outs["fp32"].shape
+    e_fold, e_plain = rel_l2(outs["fold"], outs["fp32"]), rel_l2(outs["plain"], outs["fp32"])
+    print("cnet encoder rel-L2 vs fp32: folded %.3e, separate passes %.3e" % (e_fold, e_plain))
+    assert e_fold < 2e-2 and e_fold < 1.5 * e_plain + 1e-3, (e_fold, e_plain)
+
+
 def test_adam_three_steps(backend, synth):
     """G7: three iterations of the reference loop (loss.backward, clip_grad_norm_(5), Adam.step) through ClipAdam."""
     ops, dev, bname = backend

@@ -853,3 +853,6 @@ def test_raft_stem_conv_bf16(backend):
     got = y.float().cpu().permute(0, 3, 1, 2)
     assert got.shape == ref.shape
     assert float(((got - ref).abs() - ref.abs() * 2 ** -8).max()) < 2e-3
+    # fused ReLU (context encoder with the frozen BatchNorm folded into w / b): exactly the ReLU of the stored values
+    yr = ops.raft_stem_bf16(xd, ops.raft_stem_weight_bf16(w.to(dev)), b.to(dev), relu=True)
+    assert torch.equal(yr, torch.relu(y))

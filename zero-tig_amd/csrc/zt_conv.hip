@@ -834,6 +834,7 @@ __device__ __forceinline__ void conv_mfma_bf16_body(const ConvArgsH& a, const in
             if (a.epi == 5) return (1.f - uf) * hf + uf * r;
             if (a.epi == 1) return r * (uf > 0.f ? 1.f : 0.2f);
             if (a.epi == 2) return r * (uf > 0.f ? 1.f : 0.f);
+            if (a.epi == 6) return fmaxf(r + uf, 0.f);          // ResidualBlock: relu(x + y) (extractor.py:56)
             return r + uf;
           };
           if (whole) {                                          // registers only: no indexed local arrays (they would go to scratch)
@@ -879,7 +880,7 @@ __device__ __forceinline__ void conv_mfma_bf16_body(const ConvArgsH& a, const in
         if (ox >= a.Wo) continue;
         float v = apply_act_fast(a.alpha * (acc[m][q][j] + b), a.act);
         const size_t pix = (size_t)(n * a.Ho + oy) * a.Wo + ox;
-        if (a.epi >= 4) {       // SepConvGRU fusions (update.py:42-58), bf16 nhwc only
+        if (a.epi == 4 || a.epi == 5) {       // SepConvGRU fusions (update.py:42-58), bf16 nhwc only
           zt_bf16* yb = (zt_bf16*)a.y;
           if (a.epi == 4) {     // [z | r] = sigmoid(conv): z is stored, r leaves as r * h
             if (co < a.esplit) yb[pix * a.ldy + co] = zt_f2bf(v);
@@ -895,6 +896,7 @@ __device__ __forceinline__ void conv_mfma_bf16_body(const ConvArgsH& a, const in
           if (a.epi == 1) v *= (u > 0.f ? 1.f : 0.2f);
           else if (a.epi == 2) v *= (u > 0.f ? 1.f : 0.f);
           else v += u;
+          if (a.epi == 6) v = fmaxf(v, 0.f);
         }
         if (a.out_mode == 1) ((float*)a.y)[((size_t)n * a.Cout + co) * a.ldy + (size_t)oy * a.Wo + ox] = v;
         else if (a.out_mode == 2) ((float*)a.y)[pix * a.ldy + co] = v;
@@ -2614,7 +2616,7 @@ static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, 
                             const void* aux, int ldaux, int epi, int variant, void* y2, int ldy2, int esplit, hipStream_t stream,
                             float* stats = nullptr, const BnBwdFuse* bnb = nullptr) {
   ZT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && out_mode >= 0 && out_mode <= 2);
-  ZT_REQUIRE(epi >= 0 && epi <= 5 && (epi < 4 || (out_mode == 0 && variant == 2)) && (epi != 4 || (y2 && esplit > 0 && esplit < Cout)));
+  ZT_REQUIRE(epi >= 0 && epi <= 6 && (epi < 4 || (out_mode == 0 && variant == 2)) && (epi != 4 || (y2 && esplit > 0 && esplit < Cout)));
   ZT_REQUIRE(ldx % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
   ZT_REQUIRE(!x2 || (csplit % HCK == 0 && ldx2 % 8 == 0 && ((uintptr_t)x2 & 15) == 0));
   ZT_REQUIRE(epi == 0 || aux);

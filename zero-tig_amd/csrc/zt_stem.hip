@@ -19,7 +19,7 @@ constexpr int ST_NT = 2;                               // 32 couts per workgroup
 
 __global__ void __launch_bounds__(256) stem7x7s2_bf16_kernel(const zt_bf16* __restrict__ x, int H, int W, const zt_bf16* __restrict__ w,
                                                              const float* __restrict__ bias, zt_bf16* __restrict__ y, int ldy, int Ho,
-                                                             int Wo, int tilesY) {
+                                                             int Wo, int tilesY, int relu) {
   __shared__ __attribute__((aligned(16))) zt_bf16 xs[ST_IR * ST_IC * 8];
   __shared__ __attribute__((aligned(16))) zt_bf16 ws[7 * ST_NT * 16 * ST_WP];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -82,7 +82,10 @@ __global__ void __launch_bounds__(256) stem7x7s2_bf16_kernel(const zt_bf16* __re
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ox = ox0 + m * 16 + l4 * 4 + j;
-        if (ox < Wo) yn[((size_t)oy * Wo + ox) * ldy + co] = zt_f2bf(acc[m][q][j] + bias_q[q]);
+        if (ox < Wo) {
+          const float v = acc[m][q][j] + bias_q[q];
+          yn[((size_t)oy * Wo + ox) * ldy + co] = zt_f2bf(relu ? fmaxf(v, 0.f) : v);
+        }
       }
   }
 }
@@ -107,13 +110,13 @@ extern "C" int zt_repack_stem_weight_bf16(const float* src, void* dst, hipStream
 }
 
 extern "C" int zt_raft_stem_conv_bf16(const void* x, int N, int H, int W, const void* w, const float* bias, void* y, int ldy,
-                                      hipStream_t stream) {
+                                      int relu, hipStream_t stream) {
   ZT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && ldy >= 64 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   const int tilesX = zt_cdiv(Wo, ST_TOW), tilesY = zt_cdiv(Ho, ST_TOH);
   ZT_REQUIRE((long long)tilesY * N <= 65535);
   hipLaunchKernelGGL(stem7x7s2_bf16_kernel, dim3(tilesX, 64 / (ST_NT * 16), tilesY * N), dim3(256), 0, stream, (const zt_bf16*)x, H, W,
-                     (const zt_bf16*)w, bias, (zt_bf16*)y, ldy, Ho, Wo, tilesY);
+                     (const zt_bf16*)w, bias, (zt_bf16*)y, ldy, Ho, Wo, tilesY, relu);
   ZT_LAUNCH_CHECK();
   return ZT_OK;
 }

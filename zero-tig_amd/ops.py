@@ -415,12 +415,12 @@ class Ops:
         self.lib.call("zt_repack_stem_weight_bf16", w, out, self._s(w))
         return out
 
-    def raft_stem_bf16(self, x, wstem, bias):
-        """x: nhwc [N,H,W,8] bf16 (channels 3..7 zero) -> conv7x7 s2 p3 + bias: nhwc [N,H/2,W/2,64] bf16 (extractor.py:120)"""
+    def raft_stem_bf16(self, x, wstem, bias, relu=False):
+        """x: nhwc [N,H,W,8] bf16 (channels 3..7 zero) -> conv7x7 s2 p3 + bias (+ ReLU): nhwc [N,H/2,W/2,64] bf16 (extractor.py:120)"""
         assert x.dtype == torch.bfloat16 and x.shape[-1] == 8 and x.is_contiguous()
         N, H, W, _ = x.shape
         out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), dtype=torch.bfloat16, device=x.device)
-        self.lib.call("zt_raft_stem_conv_bf16", x, N, H, W, wstem, bias, out, 64, self._s(x))
+        self.lib.call("zt_raft_stem_conv_bf16", x, N, H, W, wstem, bias, out, 64, int(relu), self._s(x))
         return out
 
     def corr_pyramid(self, corr0, h, w):
@@ -515,7 +515,7 @@ class Ops:
             assert av.t.dtype == torch.bfloat16
             auxp, ldaux = av.ptr, av.ld
         tok = self._ev_begin(self.profile["match"].get((KH, KW, stride, Cin, Cout, x.H, x.W))) if self.profile else None
-        if epi >= 4:            # fused SepConvGRU epilogues
+        if epi >= 4:            # fused SepConvGRU epilogues (4, 5); ResidualBlock tail relu(act(conv) + aux) (6)
             o2 = _cv(out2) if out2 is not None else None
             assert o2 is None or o2.t.dtype == torch.bfloat16
             self.lib.call("zt_conv2d_nhwc_bf16_ex", x.ptr, x2p, csplit, x.ld, ldx2, x.N, x.H, x.W, Cin,

@@ -114,6 +114,25 @@ class RaftPlan:
                 sc, sh, _, _ = o.norm_finalize(None, 1, C, 1, 2, self._w(name + ".weight"), self._w(name + ".bias"),
                                                self._w(name + ".running_mean"), self._w(name + ".running_var"), dev=self.dev)
                 self.bn[name] = (sc, sh)
+        # bf16 mode: that scale / shift goes into the weights and bias of the conv in front of it (conv1 -> norm1, conv2 -> norm2,
+        # downsample.0 -> norm3), the ReLUs and the residual add into that conv's epilogue: the context encoder's 14 normalisation
+        # passes after the stem disappear (ZT_RAFT_FOLD_BN=0: separate passes, the A/B and the fp32 plan's form)
+        self.folded = {}
+        if self.h and os.environ.get("ZT_RAFT_FOLD_BN", "1") != "0":
+            for name, (sc, sh) in list(self.bn.items()):
+                if name == "cnet.norm1":                         # stem: relu(norm1(conv1(x))), extractor.py:168-170
+                    w = self._w("cnet.conv1.weight").float() * sc.view(-1, 1, 1, 1)
+                    self.wstem["cnet#bn"] = o.raft_stem_weight_bf16(w.contiguous())
+                    self.W[self.pre + ".cnet.conv1#bn.bias"] = (self._w("cnet.conv1.bias").float() * sc + sh).contiguous()
+                    continue
+                if not name.startswith("cnet.layer"):
+                    continue
+                blk, nrm = name.rsplit(".", 1)
+                conv = blk + {"norm1": ".conv1", "norm2": ".conv2", "norm3": ".downsample.0"}[nrm]
+                w = self._w(conv + ".weight").float() * sc.view(-1, 1, 1, 1)
+                self.wd[conv + "#bn"] = rp(w.contiguous())
+                self.W[self.pre + "." + conv + "#bn.bias"] = (self._w(conv + ".bias").float() * sc + sh).contiguous()
+                self.folded[conv] = True
 
     # ------------------------------------------------------------------------------------------------ building blocks
     def _conv(self, x, name, cout, k, stride=1, pad=None, act=None, alpha=1.0, out=None, x2=None, out_f32=False, bias=True, row0=0,
@@ -144,6 +163,10 @@ class RaftPlan:
         return o.norm_apply(y, sc, sh, res=res, inner_relu=inner_relu, outer_relu=outer_relu)
 
     def _res_block(self, p, x, dim, stride, kind):
+        if kind == "batch" and self.folded.get(p + ".conv1"):
+            y = self._conv(x, p + ".conv1#bn", dim, 3, stride, act="relu")
+            xs = self._conv(x, p + ".downsample.0#bn", dim, 1, stride, pad=(0, 0)) if stride != 1 else x
+            return self._conv(y, p + ".conv2#bn", dim, 3, 1, act="relu", aux=xs, epi=6)
         y = self._conv(x, p + ".conv1", dim, 3, stride)
         y = self._norm(y, p + ".norm1", kind, True)
         y = self._conv(y, p + ".conv2", dim, 3, 1)
@@ -156,11 +179,17 @@ class RaftPlan:
 
     def _encoder(self, enc, x, kind):
         """extractor.py:117-191 up to (not including) the 1x1 output conv."""
+        skip_norm1 = False
         if self.h and x.shape[-1] == 8:       # bf16 mode: dedicated stem kernel (7 px x 8 ch of a kernel row = one 64-wide K range)
-            y = self.ops.raft_stem_bf16(x, self.wstem[enc], self._w(enc + ".conv1.bias"))
+            if kind == "batch" and (enc + "#bn") in self.wstem:
+                y = self.ops.raft_stem_bf16(x, self.wstem[enc + "#bn"], self._w(enc + ".conv1#bn.bias"), relu=True)
+                skip_norm1 = True
+            else:
+                y = self.ops.raft_stem_bf16(x, self.wstem[enc], self._w(enc + ".conv1.bias"))
         else:
             y = self._conv(CV(x, 0, 3), enc + ".conv1", 64, 7, 2)
-        y = self._norm(y, enc + ".norm1", kind, True)
+        if not skip_norm1:
+            y = self._norm(y, enc + ".norm1", kind, True)
         for li, dim, stride in ((1, 64, 1), (2, 96, 2), (3, 128, 2)):
             y = self._res_block("%s.layer%d.0" % (enc, li), y, dim, stride, kind)
             y = self._res_block("%s.layer%d.1" % (enc, li), y, dim, 1, kind)
