@@ -274,11 +274,15 @@ def main():
         if a.precision == "bf16":
             # bf16: 288 FLOP/B sits at the ridge (2500 TF / 8 TB/s = 312); priced against HBM.  Per launch the kernel reads the
             # 64-ch bf16 input once and writes the 64-ch output once (the three dgrad launches also read the residual df).
-            alg = (3 * (2 * px * 64 * 2) + 3 * (3 * px * 64 * 2)) / 6.0
+            # With the BatchNorm-backward sums fused in (zero-tig_amd/engine.py: default at this size), two of the three dgrad
+            # launches also read the previous block's pre-activation z once -- the read of the separate statistics pass they replace.
+            fused_bn = os.environ.get("ZT_FUSED_BN_BWD", "1") == "1" and \
+                ((W + 31) // 32) * ((H + 7) // 8) >= int(os.environ.get("ZT_STATS_FUSE_MIN_TILES", "1024"))
+            alg = (3 * (2 * px * 64 * 2) + 3 * (3 * px * 64 * 2) + (2 * px * 64 * 2 if fused_bn else 0)) / 6.0
             gbs = alg / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "conv_rs_bf16_kernel<2,2,true,2,0,*> (Enhancer 64->64 3x3: 3 fwd + 3 dgrad launches per step)",
                     "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                    "launches": nl, "avg_ms": ms, "algorithmic_bytes_per_launch": alg,
+                    "launches": nl, "avg_ms": ms, "algorithmic_bytes_per_launch": alg, "bn_backward_sums_fused": fused_bn,
                     "mfma_view": {"achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_BF16_MFMA_TFLOPS, "frac": tf / PEAK_BF16_MFMA_TFLOPS,
                                   "algorithmic_flops_per_launch": flops}}
             try:        # NOT measured in this run: HBM traffic of the same kernels from the committed PMC passes (profiles/)

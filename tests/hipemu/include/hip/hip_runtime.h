@@ -295,6 +295,8 @@ static inline void zt_emu_glds(const void* g, void* lds_base, int size) {
 #define ZT_GLDS16_HIDDEN(g, l) zt_emu_glds((const void*)(g), (void*)(l), 16)
 #define ZT_WAIT_HIDDEN_DMA() ((void)0)
 #define ZT_VMAX(a, b) fmaxf((a), (b))
+#define ZT_HIDDEN_LD16(dst, ptr) ((dst) = *reinterpret_cast<const zt_u32x4*>(ptr))
+#define ZT_HIDDEN_WAIT4(N, a, b, c, d) ((void)0)
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) zt_emu_glds((const void*)(g), (void*)(l), (size))
 
 // ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per 16-lane group, lane 4q+p supplies the address of row q, columns

@@ -206,6 +206,18 @@ __device__ __forceinline__ float zt_vmax_(float a, float b) {
 #define ZT_VMAX(a, b) zt_vmax_((a), (b))
 #endif
 
+// 16-byte global loads whose completion the KERNEL waits for, not the compiler: hipcc's wait insertion is conservative at control-
+// flow joins (a load issued before a conditionally executed block of LDS-DMAs gets `vmcnt(0)` at its first use, i.e. it also waits
+// for every DMA issued after it).  ZT_HIDDEN_LD16 issues the load from inline asm (the compiler believes dst is ready);
+// ZT_HIDDEN_WAIT4<N> is `s_waitcnt vmcnt(N)` tied to the four destinations, so no use can be scheduled above it.  Between the
+// two the destinations must not be read, copied or spilled -- check the .s after touching such code.  The host-side test
+// emulator pre-defines both (plain load / no-op).
+typedef unsigned zt_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef ZT_HIDDEN_LD16
+#define ZT_HIDDEN_LD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr))
+#define ZT_HIDDEN_WAIT4(N, a, b, c, d) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N))
+#endif
+
 // make a value opaque to the optimiser (keeps per-iteration address arithmetic from being hoisted out of a persistent loop and
 // spilled).  The host-side test emulator pre-defines it as a no-op.
 #ifndef ZT_OPAQUE

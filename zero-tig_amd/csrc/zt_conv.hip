@@ -1651,6 +1651,27 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
       zt_glds16(a.aux + (unsigned)((oy * a.Wo + ox) * a.ldaux + ch * 8), st[buf] + (i * RT + wave) * 512);
     }
   };
+  // AUXS: the aux chunks (and the BatchNorm pre-activations of BSTATS) of tile k straight from global, 16 bytes per lane, all in
+  // flight -- issued BEFORE the next halo's DMAs: vector-memory operations complete in order, so the store phase's wait for these
+  // loads would otherwise also wait for the whole halo that was issued in front of them (a full HBM round trip per tile)
+  // (BSTATS keeps 32 registers of operands per lane: holding them across the DMA address arithmetic spills, and a scratch reload
+  // is itself a vector-memory operation behind the DMAs -- there the loads stay inside the store phase, behind the halo issue)
+  constexpr bool AUXE = AUXS && !BSTATS;
+  static_assert(!AUXE || NOUT == 4, "hidden aux loads are waited for four at a time");
+  zt_u32x4 uxe[AUXE ? NOUT : 1];
+  auto aux_fetch = [&](int k) {
+    int ty, tx;
+    tile_xy(k, ty, tx);
+    const int oy0 = ty * RTH, ox0 = tx * TW;
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+      const int e = tid + i * NTHR, pl = e / CH8, ch = e % CH8;
+      int oy = oy0 + pl / TW, ox = ox0 + pl % TW;
+      oy = oy >= a.Ho ? a.Ho - 1 : oy;
+      ox = ox >= a.Wo ? a.Wo - 1 : ox;
+      ZT_HIDDEN_LD16(uxe[AUXE ? i : 0], a.aux + (unsigned)((oy * a.Wo + ox) * a.ldaux + ch * 8));
+    }
+  };
   auto store_tile = [&](int k, bool halo_in_flight = false) {
     int ty, tx;
     tile_xy(k, ty, tx);
@@ -1662,21 +1683,29 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
       if (halo_in_flight) zt_wait_vmcnt<GLDS ? NGL : NPF>();
       else zt_wait_vmcnt0();
     }
-    uint4 v[NOUT], ux[AUXS ? NOUT : 1], zx[BSTATS ? NOUT : 1];
+    uint4 v[NOUT], ux[BSTATS ? NOUT : 1], zx[BSTATS ? NOUT : 1];
     float ssum[STATS ? 8 : 1], ssq[STATS ? 8 : 1];
     if constexpr (STATS) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) ssum[c] = ssq[c] = 0.f;
     }
-    if constexpr (AUXS) {                                       // aux chunks straight from global (16 bytes per lane), all in flight
+    if constexpr (AUXE) {
+      // the aux loads of aux_fetch(k) were issued before the NGL halo DMAs of tile k + 2 (the last of which a wave may skip): all
+      // but those may still be in flight
+      // (one register-tied wait on every path -- two alternatives would meet in copies of the still pending registers; the drain
+      // for the tiles without a following halo is a separate, untied statement in front of it)
+      if (!(GLDS && k + 2 < n_my && !(a.dbg & 4)) || (a.dbg & 128)) ZT_WAIT_HIDDEN_DMA();
+      ZT_HIDDEN_WAIT4(GLDS ? NGL - 1 : 0, uxe[0], uxe[AUXE ? 1 : 0], uxe[AUXE ? 2 : 0], uxe[AUXE ? 3 : 0]);
+    }
+    if constexpr (BSTATS) {                                     // aux chunks + pre-activations straight from global (16 bytes per lane), all in flight
 #pragma unroll
       for (int i = 0; i < NOUT; ++i) {
         const int e = tid + i * NTHR, pl = e / CH8, ch = e % CH8;
         int oy = oy0 + pl / TW, ox = ox0 + pl % TW;
         oy = oy >= a.Ho ? a.Ho - 1 : oy;
         ox = ox >= a.Wo ? a.Wo - 1 : ox;
-        ux[AUXS ? i : 0] = *reinterpret_cast<const uint4*>(a.aux + (unsigned)((oy * a.Wo + ox) * a.ldaux + ch * 8));
-        if constexpr (BSTATS) zx[BSTATS ? i : 0] = *reinterpret_cast<const uint4*>(a.zprev + (unsigned)((oy * a.Wo + ox) * a.ldz + ch * 8));
+        ux[BSTATS ? i : 0] = *reinterpret_cast<const uint4*>(a.aux + (unsigned)((oy * a.Wo + ox) * a.ldaux + ch * 8));
+        zx[BSTATS ? i : 0] = *reinterpret_cast<const uint4*>(a.zprev + (unsigned)((oy * a.Wo + ox) * a.ldz + ch * 8));
       }
     }
     if (!AUXL) {                                                // AUXL runs mid-loop with every accumulator live: one chunk at a time
@@ -1698,7 +1727,8 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
           u = *reinterpret_cast<const uint4*>(ab + e * 8);
         } else {
           o = v[i];
-          u = ux[AUXS ? i : 0];
+          if constexpr (BSTATS) u = ux[BSTATS ? i : 0];
+          else u = make_uint4(uxe[AUXE ? i : 0].x, uxe[AUXE ? i : 0].y, uxe[AUXE ? i : 0].z, uxe[AUXE ? i : 0].w);
         }
         const unsigned vv[4] = {o.x, o.y, o.z, o.w}, uu[4] = {u.x, u.y, u.z, u.w};
         unsigned oo[4];
@@ -1806,7 +1836,13 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
       if (k >= 1) glds_aux(k - 1, k & 1);
       if (k + 1 < n_my && !(a.dbg & 4)) load_halo(k + 1);
     } else {
+      if constexpr (AUXE) {
+        if (k >= 1 && !(a.dbg & 2) && !(a.dbg & 128)) aux_fetch(k - 1);
+      }
       if (k + 1 < n_my && !(a.dbg & 4)) load_halo(k + 1);
+      if constexpr (AUXE) {                                     // A/B form (ZT_RS_AUX_LATE=1): aux loads behind the halo issue, full drain
+        if (k >= 1 && !(a.dbg & 2) && (a.dbg & 128)) aux_fetch(k - 1);
+      }
       if (k >= 1 && !(a.dbg & 2)) store_tile(k - 1);
       if constexpr (NST == 1) ZT_LDS_BARRIER();                 // single staging buffer: every wave has read tile k-1 before tile k is staged
     }
@@ -1907,6 +1943,7 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
   }
   if (n_my > 0) {
     if (AUXL) glds_aux(n_my - 1, n_my & 1);
+    if constexpr (AUXE) aux_fetch(n_my - 1);
     store_tile(n_my - 1);
   }
   if constexpr (STATS) {
@@ -2631,7 +2668,8 @@ static int conv2d_bf16_impl(const void* x, const void* x2, int csplit, int ldx, 
   a.zprev = nullptr; a.ldz = 0; a.bn_scale = a.bn_shift = a.bn_mean = nullptr;
   if (bnb) { a.zprev = (const zt_bf16*)bnb->zprev; a.ldz = bnb->ldz; a.bn_scale = bnb->scale; a.bn_shift = bnb->shift; a.bn_mean = bnb->mean; }
   static const int scalar_epi = getenv("ZT_TILED_SCALAR_EPI") ? atoi(getenv("ZT_TILED_SCALAR_EPI")) : 0;   // A/B knob: per-element epilogue
-  a.dbg = (variant >= 64 ? (variant - 64) : (variant >= 32 ? (variant - 32) : (variant >= 16 ? (variant - 16) : 0))) | (scalar_epi ? 32 : 0);   // tuning ablations, see tools/bench_conv.py / bench_small.py
+  static const int aux_late = getenv("ZT_RS_AUX_LATE") ? atoi(getenv("ZT_RS_AUX_LATE")) : 0;              // A/B knob: conv_rs aux loads behind the halo DMAs
+  a.dbg = (aux_late ? 128 : 0) | (variant >= 64 ? (variant - 64) : (variant >= 32 ? (variant - 32) : (variant >= 16 ? (variant - 16) : 0))) | (scalar_epi ? 32 : 0);   // tuning ablations, see tools/bench_conv.py / bench_small.py
   if (variant >= 64) variant = 2;
   if (variant >= 32) variant = 3;
   if (variant >= 16) variant = 1;
