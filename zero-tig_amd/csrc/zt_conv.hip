@@ -1581,6 +1581,22 @@ __global__ void __launch_bounds__(64 * RT, RT == 4 ? 2 : 1) conv_rs_bf16_kernel(
     }
     int ln = lane;
     ZT_OPAQUE(ln);                                              // recompute the slot geometry per tile instead of keeping it in registers
+    if constexpr (!FASTSLOT && !BSTATS) {                       // (BSTATS: the second code path costs it two spilled registers)
+      // EPI instantiations: interior tiles without the precomputed offsets -- the same address as the general path minus its
+      // clamps, bounds tests and selects (35 -> ~12 vector instructions per DMA; the kernel is issue-co-limited, section 5)
+      if (gy0 >= 0 && gy0 + IR <= a.H && gx0 >= 0 && gx0 + IC <= a.W) {
+        const zt_bf16* base = a.x + (unsigned)((gy0 * a.W + gx0) * a.ldx);
+#pragma unroll
+        for (int i = 0; i < NGL; ++i) {
+          const int e = (i * RT + wave) * 64 + ln;
+          const int p = e >> 3, row = p / IC, col = p - row * IC;
+          const int cj = (e & 7) ^ (col & 7);
+          const void* src = cj * 8 < a.Cin ? (const void*)(base + (unsigned)((row * a.W + col) * a.ldx + cj * 8)) : (const void*)&zt_zero_chunk;
+          if (i * NTHR + NTHR - 1 < IR * IC * 8 || e < IR * IC * 8) zt_glds16(src, xb + (i * RT + wave) * 512);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NGL; ++i) {
       const int e = (i * RT + wave) * 64 + ln;
